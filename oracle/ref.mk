@@ -1,0 +1,52 @@
+# oracle/ref.mk -- builds the REAL reference (tangkk/audiomod phase-vocoder path)
+# from its own sources where they lie under $(REF) into oracle/_ref/ (git-ignored).
+#
+# TEST INFRASTRUCTURE ONLY.  Nothing here is shipped or linked into the product
+# library.  No reference source is copied into this repository: the compiler reads the
+# files in place.  The reference's own build system (CMake) is NOT run; this is a
+# short hand-written recipe with the same effective flags the reference's Release
+# build uses (-O3 -DNDEBUG -std=gnu++14, baseline x86-64 => no FMA contraction).
+#
+#   make -f oracle/ref.mk            (from the repo root; needs /root/reference)
+#
+REF ?= /root/reference
+OUT := oracle/_ref
+CXX := g++
+CC  := gcc
+CXXFLAGS := -O3 -DNDEBUG -std=gnu++14 -fPIC -w
+CFLAGS   := -O3 -DNDEBUG -fPIC -w
+INC := -I$(REF)/src -I$(REF)/include -I$(REF)/include/dafx
+
+# Only the files the phase-vocoder path needs (SURVEY.md section 2, rows 1-13 + 16).
+CXXSRC := $(wildcard $(REF)/src/phasevocoder/*.cc) \
+          $(REF)/src/common/dsp/FFT.cc $(REF)/src/common/dsp/resampler.cc \
+          $(REF)/src/common/system/sys.cc \
+          $(wildcard $(REF)/src/common/gen/*.cc)
+CSRC   := $(wildcard $(REF)/src/common/kissfft/*.c) $(REF)/src/common/speex/resample.c
+
+CXXOBJ := $(patsubst $(REF)/%.cc,$(OUT)/obj/%.o,$(CXXSRC))
+COBJ   := $(patsubst $(REF)/%.c,$(OUT)/obj/%.o,$(CSRC))
+
+all: $(OUT)/ref_driver $(OUT)/ref_kat
+
+$(OUT)/obj/%.o: $(REF)/%.cc
+	@mkdir -p $(dir $@)
+	$(CXX) $(CXXFLAGS) $(INC) -c $< -o $@
+
+$(OUT)/obj/%.o: $(REF)/%.c
+	@mkdir -p $(dir $@)
+	$(CC) $(CFLAGS) $(INC) -c $< -o $@
+
+$(OUT)/libaudiomod_ref.a: $(CXXOBJ) $(COBJ)
+	ar rcs $@ $^
+
+# ref_driver.cc / ref_kat.cc are OUR code: thin callers of the reference's public API.
+$(OUT)/ref_driver: oracle/ref_driver.cc $(OUT)/libaudiomod_ref.a
+	$(CXX) $(CXXFLAGS) $(INC) $< $(OUT)/libaudiomod_ref.a -o $@ -static-libstdc++ -static-libgcc -lpthread -ldl
+
+$(OUT)/ref_kat: oracle/ref_kat.cc $(OUT)/libaudiomod_ref.a
+	$(CXX) $(CXXFLAGS) $(INC) $< $(OUT)/libaudiomod_ref.a -o $@ -static-libstdc++ -static-libgcc -lpthread -ldl
+
+clean:
+	rm -rf $(OUT)
+.PHONY: all clean
