@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference compiled into oracle/_ref/.
+
+Run in the build container only (needs /root/reference for `make -f oracle/ref.mk`):
+    python tools/make_golden.py
+Each fixture is DATA: int16-grid inputs, the reference's float32 outputs, and the per-call
+availability counts.  No reference source travels.  tests/test_oracle_golden.py pins
+oracle/pv_oracle.c against these on any host; tests/test_gpu_parity.py pins the HIP engine.
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from audiomod_amd import signals  # noqa: E402
+from oracle import oracle_py as O  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+FRAMES = 16000
+
+E2E = [
+    # name, signal, kwargs for the drive
+    ("cfg2_shift+4_cm1_stereo", "voice2", dict(mode="normal_pitchshift", semitones=4.0, coremode=1, fftsize=2048)),
+    ("shift+4_cm0_stereo", "voice2", dict(mode="normal_pitchshift", semitones=4.0, coremode=0, fftsize=2048)),
+    ("shift+4_cm2_stereo", "voice2", dict(mode="normal_pitchshift", semitones=4.0, coremode=2, fftsize=2048)),
+    ("cfg1_shift+4_cm1_mono", "voice1", dict(mode="normal_pitchshift", semitones=4.0, coremode=1, fftsize=2048)),
+    ("cfg3_stretch1.5_cm1_4096", "voice2", dict(mode="time_stretch", time_ratio=1.5, coremode=1, fftsize=4096, flush=False)),
+    ("cfg4_formant+7", "voice2", dict(mode="formant_pitchshift", semitones=7.0, coremode=1, fftsize=2048)),
+    ("cfg4_formant-7", "voice2", dict(mode="formant_pitchshift", semitones=-7.0, coremode=1, fftsize=2048)),
+    ("cfg4_gender+7", "voice2", dict(mode="gender_change", semitones=7.0, coremode=1, fftsize=2048)),
+    ("cfg4_gender-7", "voice2", dict(mode="gender_change", semitones=-7.0, coremode=1, fftsize=2048)),
+    ("dualmono_shift+4_cm1", "dual", dict(mode="normal_pitchshift", semitones=4.0, coremode=1, fftsize=2048)),
+    ("silenceburst_shift+4_cm1", "burst", dict(mode="normal_pitchshift", semitones=4.0, coremode=1, fftsize=2048)),
+    ("shift+12_intratio", "voice2", dict(mode="normal_pitchshift", semitones=12.0, coremode=1, fftsize=2048)),
+    ("sweep_shift-3_cm0", "sweep", dict(mode="normal_pitchshift", semitones=-3.0, coremode=0, fftsize=2048)),
+    ("rt_shift+4_cm1", "voice2", dict(api="rt", mode="normal_pitchshift", semitones=4.0, coremode=1, fftsize=2048)),
+]
+
+
+def make_signal(kind):
+    if kind == "voice2":
+        return signals.voice(FRAMES, 2)
+    if kind == "voice1":
+        return signals.voice(FRAMES, 1)
+    if kind == "dual":
+        return signals.dual_mono(FRAMES)
+    if kind == "burst":
+        return signals.silence_burst(FRAMES * 2)
+    if kind == "sweep":
+        return signals.sweep(FRAMES)
+    raise ValueError(kind)
+
+
+def main():
+    if not os.path.isdir("/root/reference"):
+        sys.exit("needs /root/reference (build container only)")
+    subprocess.check_call(["make", "-s", "-f", "oracle/ref.mk"], cwd=ROOT)
+    os.makedirs(GOLD, exist_ok=True)
+
+    for name, kind, kw in E2E:
+        x = make_signal(kind)
+        xi = np.round(x * 32768.0).astype(np.int16)
+        assert np.array_equal(xi.astype(np.float32) / 32768.0, x)
+        y, counts = O.ref_run(x, **kw)
+        meta = {k: v for k, v in kw.items()}
+        np.savez_compressed(os.path.join(GOLD, f"e2e_{name}.npz"), x_i16=xi, y=y, counts=np.array(counts, np.int32),
+                            meta=np.array(repr(meta)))
+        print(f"e2e_{name}: in {x.shape} out {y.shape} calls {len(counts)}")
+
+    # ---- unit KATs ----
+    rng = np.random.default_rng(4242)
+    kat = {}
+    with tempfile.TemporaryDirectory() as d:
+        p = lambda n: os.path.join(d, n)
+        for N in (2048, 4096):
+            O.ref_kat("win", N, p("w.f32"))
+            w = np.fromfile(p("w.f32"), np.float32)
+            kat[f"hann{N}"] = w[:N]
+            kat[f"hann{N}_area"] = w[N:]
+            H = N // 2 + 1
+            frames = np.stack([
+                signals.voice(N, 1, seed=5)[0],
+                rng.uniform(-1, 1, N).astype(np.float32),
+                np.zeros(N, np.float32),
+                np.concatenate([[1.0], np.zeros(N - 1)]).astype(np.float32),
+            ])
+            frames.tofile(p("f.f32"))
+            O.ref_kat("fwd", N, len(frames), p("f.f32"), p("mp.f32"))
+            mp = np.fromfile(p("mp.f32"), np.float32).reshape(len(frames), 2, H)
+            kat[f"fwd{N}_in"] = frames
+            kat[f"fwd{N}_magphase"] = mp
+            # inverse: realistic polar spectra with unwrapped (large) phases as freqComp makes them
+            mag = np.abs(rng.normal(0, 1, (3, H))).astype(np.float32) / N
+            ph = rng.uniform(-300, 300, (3, H)).astype(np.float32)
+            ph[0] = mp[0, 1]
+            pol = np.stack([mag, ph], axis=1).astype(np.float32)
+            pol.tofile(p("pol.f32"))
+            O.ref_kat("inv", N, 3, p("pol.f32"), p("t.f32"))
+            kat[f"inv{N}_in"] = pol
+            kat[f"inv{N}_out"] = np.fromfile(p("t.f32"), np.float32).reshape(3, N)
+        # resampler: the three config ratios + an exact 0.5 (direct table) + chunks as the PV feeds them
+        sig = signals.voice(6000, 1, seed=11)[0]
+        sig.tofile(p("r.f32"))
+        kat["res_in"] = sig
+        for tag, ps, chunks in (("+4", 2.0 ** (np.float32(4.0) / np.float32(12.0)), (256, 255, 256, 256, 257)),
+                                ("+7", 2.0 ** (np.float32(7.0) / np.float32(12.0)), (256, 255)),
+                                ("-7", 2.0 ** (np.float32(-7.0) / np.float32(12.0)), (303, 304, 303)),
+                                ("+12", 2.0, (406,))):
+            ratio = np.float32(1.0 / np.float32(ps))
+            O.ref_kat("res", repr(float(ratio)), len(sig), p("r.f32"), p("ro.f32"), p("rc.txt"), *chunks)
+            kat[f"res{tag}_ratio"] = np.array([ratio], np.float32)
+            kat[f"res{tag}_chunks"] = np.loadtxt(p("rc.txt"), dtype=np.int32).reshape(-1, 2)
+            kat[f"res{tag}_out"] = np.fromfile(p("ro.f32"), np.float32)
+    np.savez_compressed(os.path.join(GOLD, "kat_units.npz"), **kat)
+    print("kat_units:", {k: v.shape for k, v in kat.items()})
+
+
+if __name__ == "__main__":
+    main()
