@@ -1,0 +1,28 @@
+# Builds the product library (HIP kernels + host engine + C ABI) for gfx950 only, in-tree.
+#   make            -> audiomod_amd/lib/libaudiomod_pv.so
+#   make oracle     -> oracle/libpv_oracle.so (test infrastructure)
+#   make ref        -> oracle/_ref/* (the real reference; only where /root/reference exists)
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  := gfx950
+# -ffp-contract=off is part of the numerical contract (see pv_kernels.hip header): no FMA contraction,
+# on the device or in the host planner.
+CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -Iaudiomod_amd/csrc -Wall -Wno-unused-result
+SRC := audiomod_amd/csrc/pv_kernels.hip audiomod_amd/csrc/pv_engine.cc audiomod_amd/csrc/pv_plan.cc audiomod_amd/csrc/phasevocoder.cc
+HDR := $(wildcard audiomod_amd/csrc/*.h) $(wildcard include/*.h) $(wildcard include/dafx/*.h)
+LIB := audiomod_amd/lib/libaudiomod_pv.so
+
+all: $(LIB)
+
+$(LIB): $(SRC) $(HDR)
+	@mkdir -p audiomod_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -shared $(SRC) -o $@
+
+oracle:
+	$(MAKE) -C oracle
+
+ref:
+	$(MAKE) -f oracle/ref.mk
+
+clean:
+	rm -rf audiomod_amd/lib
+.PHONY: all oracle ref clean

@@ -1,0 +1,772 @@
+// pv_engine.cc -- host engine + C ABI (include/audiomod_pv.h) of the MI355X phase-vocoder.
+//
+// The host stages overlapping STFT frames across channels / blocks / streams and drives the four
+// gfx950 kernels of pv_kernels.hip chunk by chunk.  All data-independent decisions (hop sizes,
+// per-slice shift increments, output counts, OLA tile geometry) come from the integer planner in
+// pv_plan.cc; the device never needs a host round trip inside a chunk.
+//
+// There is NO CPU fallback: without a gfx950 device every constructor returns PV_ERR_NO_DEVICE.
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "audiomod_pv.h"
+#include "pv_kernels.h"
+#include "pv_plan.h"
+
+namespace pv {
+
+static thread_local std::string g_last_error;
+
+static int hip_fail(hipError_t e, const char *what, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s failed at pv_engine.cc:%d: %s", what, line, hipGetErrorString(e));
+    g_last_error = buf;
+    return PV_ERR_HIP;
+}
+#define HIPC(call)                                                 \
+    do {                                                           \
+        hipError_t e__ = (call);                                   \
+        if (e__ != hipSuccess) return hip_fail(e__, #call, __LINE__); \
+    } while (0)
+
+static int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+static int next_pow2_i(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+static int count_gfx950() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    int alloc(size_t count) {
+        release();
+        n = count;
+        HIPC(hipMalloc((void **)&p, (count ? count : 1) * sizeof(T)));
+        return PV_OK;
+    }
+    int upload(const std::vector<T> &v) {
+        int st = alloc(v.size());
+        if (st != PV_OK) return st;
+        if (!v.empty()) HIPC(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return PV_OK;
+    }
+};
+
+template <typename T> struct PinBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~PinBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    int alloc(size_t count) {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = count;
+        HIPC(hipHostMalloc((void **)&p, (count ? count : 1) * sizeof(T), hipHostMallocDefault));
+        return PV_OK;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Core: device-resident tables, intermediates and per-stream state for S streams x C channels.
+// ------------------------------------------------------------------------------------------
+struct Core {
+    Derived d;
+    int device = 0, S = 0, C = 0, rows = 0;
+    int Tc = 0, FR = 0, HP = 0, pkmax = 0, lookback = 0;
+    int ola_lds_floats = 0;
+    DevTables tb{};
+    DevBuf<int32_t> perm, iperm;
+    DevBuf<float2> tw_fwd, tw_inv, st_fwd, st_inv;
+    DevBuf<float> window, sinc;
+    DevBuf<float> mag, phase, frames, st_prev_phase, st_prev_out;
+    DevBuf<int32_t> st_peaks, st_npeaks;
+
+    int init(const pv_config &cfg, int dev, int nstreams, int chunk_slices);
+    int reset_state(hipStream_t st);
+    // tile geometry for outputs [ka, kb) given the slice table (P of slice t = slices[t - t_base].P)
+    int build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64_t t_end, int64_t ka, int64_t kb,
+                    int32_t p_index_base, std::vector<OlaTile> &tiles) const;
+    void launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
+                      int ntiles, const int64_t *d_P, float *out, int64_t out_stride_row, int64_t k_base,
+                      hipStream_t st, hipEvent_t *ev /* 8 events or null */) const;
+};
+
+int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
+    int st = derive(cfg, d);
+    if (st != PV_OK) return st;
+    if (d.N > 8192) {
+        g_last_error = "fftsize above 8192 is not supported by the phase kernel";
+        return PV_ERR_UNSUPPORTED;
+    }
+    if (count_gfx950() <= 0) {
+        g_last_error = "no gfx950 (MI355X) device visible: this library has no CPU fallback";
+        return PV_ERR_NO_DEVICE;
+    }
+    device = dev;
+    HIPC(hipSetDevice(dev));
+    {
+        hipDeviceProp_t p;
+        HIPC(hipGetDeviceProperties(&p, dev));
+        if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+            g_last_error = std::string("device is ") + p.gcnArchName + ", kernels are built for gfx950 only";
+            return PV_ERR_NO_DEVICE;
+        }
+    }
+    S = nstreams;
+    C = cfg.channels;
+    rows = S * C;
+    HP = d.hs + 8; // row pitch of the mag / phase planes (16-byte aligned rows)
+    pkmax = d.hs / 3 + 2;
+    if (phase_lds_bytes(d.hs, C, pkmax) > 160 * 1024 - 256) {
+        g_last_error = "channels x fftsize exceeds the phase kernel's LDS budget";
+        return PV_ERR_UNSUPPORTED;
+    }
+    // frames that can overlap one OLA tile / that must stay in the ring behind the newest slice
+    const double step = d.resample ? (double)d.res_num / (double)d.res_den : 1.0;
+    const int tile_span = (int)(kTileOut * step) + (d.resample ? d.filt_len : 0) + 4;
+    ola_lds_floats = tile_span + 4;
+    lookback = (d.N + tile_span) / d.min_shift + 3;
+    if ((tile_span + d.N) / d.min_shift + 3 > kMaxTileFrames) {
+        g_last_error = "hop too small relative to the FFT size for the OLA tile";
+        return PV_ERR_UNSUPPORTED;
+    }
+    Tc = chunk_slices;
+    FR = next_pow2_i(Tc + lookback + 1);
+
+    // tables
+    std::vector<int32_t> ip(d.fft.nc);
+    for (int j = 0; j < d.fft.nc; ++j) ip[d.fft.perm[j]] = j;
+    if ((st = perm.upload(d.fft.perm)) != PV_OK) return st;
+    if ((st = iperm.upload(ip)) != PV_OK) return st;
+    auto up2 = [&](DevBuf<float2> &b, const std::vector<cpx> &v) -> int {
+        std::vector<float2> t(v.size());
+        for (size_t i = 0; i < v.size(); ++i) t[i] = make_float2(v[i].r, v[i].i);
+        return b.upload(t);
+    };
+    if ((st = up2(tw_fwd, d.fft.tw_fwd)) != PV_OK) return st;
+    if ((st = up2(tw_inv, d.fft.tw_inv)) != PV_OK) return st;
+    if ((st = up2(st_fwd, d.fft.st_fwd)) != PV_OK) return st;
+    if ((st = up2(st_inv, d.fft.st_inv)) != PV_OK) return st;
+    if ((st = window.upload(d.window)) != PV_OK) return st;
+    if ((st = sinc.upload(d.sinc)) != PV_OK) return st;
+
+    tb.N = d.N;
+    tb.hs = d.hs;
+    tb.H = d.H;
+    tb.HP = HP;
+    tb.nc = d.fft.nc;
+    tb.log2nc = ilog2(d.fft.nc);
+    tb.nstages = d.fft.nstages;
+    for (int s = 0; s < d.fft.nstages; ++s) {
+        tb.radix[s] = d.fft.radix[s];
+        tb.log2m[s] = ilog2(d.fft.m[s]);
+        tb.fstride[s] = d.fft.fstride[s];
+    }
+    tb.perm = perm.p;
+    tb.iperm = iperm.p;
+    tb.tw_fwd = tw_fwd.p;
+    tb.tw_inv = tw_inv.p;
+    tb.st_fwd = st_fwd.p;
+    tb.st_inv = st_inv.p;
+    tb.window = window.p;
+
+    if ((st = mag.alloc((size_t)rows * Tc * HP)) != PV_OK) return st;
+    if ((st = phase.alloc((size_t)rows * Tc * HP)) != PV_OK) return st;
+    if ((st = frames.alloc((size_t)rows * FR * d.N)) != PV_OK) return st;
+    if ((st = st_prev_phase.alloc((size_t)rows * d.hs)) != PV_OK) return st;
+    if ((st = st_prev_out.alloc((size_t)rows * d.hs)) != PV_OK) return st;
+    if ((st = st_peaks.alloc((size_t)S * pkmax)) != PV_OK) return st;
+    if ((st = st_npeaks.alloc((size_t)S)) != PV_OK) return st;
+    return reset_state(nullptr);
+}
+
+int Core::reset_state(hipStream_t st) {
+    HIPC(hipMemsetAsync(st_prev_phase.p, 0, st_prev_phase.n * sizeof(float), st));
+    HIPC(hipMemsetAsync(st_prev_out.p, 0, st_prev_out.n * sizeof(float), st));
+    HIPC(hipMemsetAsync(st_npeaks.p, 0, st_npeaks.n * sizeof(int32_t), st));
+    return PV_OK;
+}
+
+int Core::build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64_t t_end, int64_t ka, int64_t kb,
+                      int32_t p_index_base, std::vector<OlaTile> &tiles) const {
+    // slices[t - t_base] must exist for every t in [max(t_base, t_end - FR), t_end); a tile that needed an
+    // older frame would be rejected below anyway (the frame ring no longer holds it)
+    int64_t t_lo = t_end - FR > t_base ? t_end - FR : t_base; // monotone cursors
+    int64_t t_hi = t_lo;
+    for (int64_t k0 = ka; k0 < kb; k0 += kTileOut) {
+        OlaTile tl{};
+        tl.k0 = k0;
+        tl.kcnt = (int32_t)((kb - k0) < kTileOut ? (kb - k0) : kTileOut);
+        int64_t n_lo, n_hi;
+        if (d.resample) {
+            auto pos = [&](int64_t k) {
+                return (int64_t)(d.filt_len / 2) + (int64_t)(((unsigned __int128)k * d.res_num) / d.res_den);
+            };
+            n_lo = pos(k0) - d.filt_len + 1;
+            n_hi = pos(k0 + tl.kcnt - 1);
+        } else {
+            n_lo = k0;
+            n_hi = k0 + tl.kcnt - 1;
+        }
+        tl.n_lo = n_lo;
+        tl.n_cnt = (int32_t)(n_hi - n_lo + 1);
+        if (tl.n_cnt > ola_lds_floats) {
+            g_last_error = "internal: OLA tile larger than its LDS budget";
+            return PV_ERR_UNSUPPORTED;
+        }
+        const int64_t n0 = n_lo < 0 ? 0 : n_lo;
+        // t_first: smallest t with P_t + N > n0 ; t_last: largest t (< t_end) with P_t <= n_hi
+        while (t_lo < t_end && slices[(size_t)(t_lo - t_base)].P + d.N <= n0) ++t_lo;
+        if (t_hi < t_lo) t_hi = t_lo;
+        while (t_hi + 1 < t_end && slices[(size_t)(t_hi + 1 - t_base)].P <= n_hi) ++t_hi;
+        if (t_lo >= t_end) {
+            g_last_error = "internal: OLA tile has no covering slice";
+            return PV_ERR_UNSUPPORTED;
+        }
+        tl.t_first = (int32_t)t_lo;
+        tl.t_cnt = (int32_t)(t_hi - t_lo + 1);
+        if (tl.t_cnt > kMaxTileFrames || t_end - t_lo > FR) {
+            g_last_error = "internal: OLA tile overlaps too many frames";
+            return PV_ERR_UNSUPPORTED;
+        }
+        tl.p_off = (int32_t)(t_lo - p_index_base);
+        tiles.push_back(tl);
+    }
+    return PV_OK;
+}
+
+void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
+                        int ntiles, const int64_t *d_P, float *out, int64_t out_stride_row, int64_t k_base,
+                        hipStream_t st, hipEvent_t *ev) const {
+    AnalyzeArgs aa{};
+    aa.tb = tb;
+    aa.ia = ia;
+    aa.hop = d.hop;
+    aa.t0 = t0;
+    aa.Tn = Tn;
+    aa.Tc = Tc;
+    aa.rows = rows;
+    aa.mag = mag.p;
+    aa.phase = phase.p;
+    if (ev) (void)hipEventRecord(ev[0], st);
+    launch_analyze(aa, st);
+    if (ev) (void)hipEventRecord(ev[1], st);
+
+    if (!d.robotic) {
+        PhaseArgs pa{};
+        pa.N = d.N;
+        pa.hs = d.hs;
+        pa.HP = HP;
+        pa.C = C;
+        pa.hop = d.hop;
+        pa.coremode = (d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0;
+        pa.two_pi_hop = d.two_pi_hop;
+        pa.t0 = t0;
+        pa.Tn = Tn;
+        pa.Tc = Tc;
+        pa.phase_inc = d_pinc;
+        pa.mag = mag.p;
+        pa.phase = phase.p;
+        pa.st_prev_phase = st_prev_phase.p;
+        pa.st_prev_out = st_prev_out.p;
+        pa.st_peaks = st_peaks.p;
+        pa.st_npeaks = st_npeaks.p;
+        pa.pkmax = pkmax;
+        if (ev) (void)hipEventRecord(ev[2], st);
+        launch_phase(pa, S, st);
+        if (ev) (void)hipEventRecord(ev[3], st);
+    }
+
+    SynthArgs sa{};
+    sa.tb = tb;
+    sa.hop = d.hop;
+    sa.two_pi_hop = d.two_pi_hop;
+    sa.do_freq_comp = d.do_freq_comp ? 1 : 0;
+    sa.freq_comp = d.freq_comp;
+    sa.fixed_gain = d.fixed_gain;
+    sa.inv_n = d.inv_n;
+    sa.robotic = d.robotic ? 1 : 0;
+    sa.t0 = t0;
+    sa.Tn = Tn;
+    sa.Tc = Tc;
+    sa.rows = rows;
+    sa.mag = mag.p;
+    sa.phase = phase.p;
+    sa.frames = frames.p;
+    sa.FR = FR;
+    if (ev) (void)hipEventRecord(ev[4], st);
+    launch_synth(sa, st);
+    if (ev) (void)hipEventRecord(ev[5], st);
+
+    if (ntiles > 0) {
+        OlaArgs oa{};
+        oa.N = d.N;
+        oa.rows = rows;
+        oa.FR = FR;
+        oa.frames = frames.p;
+        oa.window = window.p;
+        oa.win_gain = d.win_gain;
+        oa.tiles = d_tiles;
+        oa.P = d_P;
+        oa.ntiles = ntiles;
+        oa.resample = d.resample ? 1 : 0;
+        oa.interp = d.interp ? 1 : 0;
+        oa.num = d.res_num;
+        oa.den = d.res_den;
+        oa.filt_len = d.filt_len;
+        oa.oversample = d.oversample;
+        oa.sinc = sinc.p;
+        oa.sinc_len = d.resample ? (int)d.sinc.size() : 0;
+        oa.lds_floats = ola_lds_floats;
+        oa.out = out;
+        oa.out_stride_row = out_stride_row;
+        oa.k_base = k_base;
+        if (ev) (void)hipEventRecord(ev[6], st);
+        launch_ola(oa, st);
+        if (ev) (void)hipEventRecord(ev[7], st);
+    }
+}
+
+static void fill_info(const Derived &d, int64_t slices, pv_info *o) {
+    memset(o, 0, sizeof(*o));
+    o->fftsize = d.N;
+    o->hop_in = d.hop;
+    o->hop_out_nominal = d.hop_out_nominal;
+    o->outbuf_capacity = d.outbuf_cap;
+    o->pitch_scale = d.pitch_scale;
+    o->hs_ratio = d.hs_ratio;
+    o->int_ratio = d.int_ratio;
+    o->resample = d.resample;
+    if (d.resample) {
+        o->res_num = d.res_num;
+        o->res_den = d.res_den;
+        o->res_filt_len = d.filt_len;
+        o->res_oversample = d.oversample;
+        o->res_interp = d.interp;
+    }
+    o->slices = slices;
+    o->bytes_per_slice = bytes_per_slice(d);
+}
+
+} // namespace pv
+
+using namespace pv;
+
+// ------------------------------------------------------------------------------------------
+// batch engine
+// ------------------------------------------------------------------------------------------
+struct pv_batch {
+    Core core;
+    BatchPlan plan;
+    int64_t frames = 0;
+    struct Chunk {
+        int64_t t0;
+        int Tn;
+        int tile_begin, ntiles;
+    };
+    std::vector<Chunk> chunks;
+    DevBuf<int32_t> d_pinc;
+    DevBuf<int64_t> d_P;
+    DevBuf<OlaTile> d_tiles;
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool; // 8 per chunk when timing
+    size_t ev_used = 0;
+    double acc_ms[PV_NUM_KERNELS] = {0, 0, 0, 0};
+    int64_t acc_n[PV_NUM_KERNELS] = {0, 0, 0, 0};
+    ~pv_batch() {
+        for (auto e : ev_pool) (void)hipEventDestroy(e);
+    }
+};
+
+struct pv_engine {
+    Core core;
+    std::unique_ptr<Planner> planner;
+    std::vector<SliceRec> recent; // slice table window; recent[0] is slice t_base
+    int64_t t_base = 0;
+    int64_t fed = 0, uploaded = 0;
+    hipStream_t stream = nullptr;
+    int ring = 0; // device input ring length (power of two) per channel
+    DevBuf<float> d_in, d_out;
+    DevBuf<char> d_desc;
+    PinBuf<float> h_in, h_out;
+    PinBuf<char> h_desc;
+    int out_cap = 0; // per-row capacity of d_out / h_out
+    std::vector<std::vector<float>> outq; // per channel FIFO
+    size_t outq_head = 0;
+    ~pv_engine() {
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+extern "C" {
+
+const char *pv_strerror(int s) {
+    switch (s) {
+    case PV_OK: return "ok";
+    case PV_ERR_INVALID_ARG: return "invalid argument";
+    case PV_ERR_UNSUPPORTED: return "unsupported configuration";
+    case PV_ERR_NO_DEVICE: return "no gfx950 device (no CPU fallback)";
+    case PV_ERR_HIP: return "HIP runtime error";
+    case PV_ERR_OUTPUT_OVERRUN: return "output ring overrun";
+    default: return "unknown status";
+    }
+}
+
+const char *pv_last_error(void) { return g_last_error.c_str(); }
+
+int pv_device_count(void) { return count_gfx950(); }
+
+const char *pv_kernel_name(int k) {
+    static const char *n[PV_NUM_KERNELS] = {"pv_analyze_kernel", "pv_phase_kernel", "pv_synth_kernel",
+                                            "pv_ola_kernel"};
+    return (k >= 0 && k < PV_NUM_KERNELS) ? n[k] : "";
+}
+
+int pv_plan_simulate(const pv_config *cfg, const int32_t *n, int32_t ncalls, int32_t *avail, int32_t *shift,
+                     int32_t *phase, int64_t max_slices, int64_t *nslices, pv_info *info) {
+    if (!cfg || (ncalls > 0 && !n)) return PV_ERR_INVALID_ARG;
+    Derived d;
+    int st = derive(*cfg, d);
+    if (st != PV_OK) return st;
+    Planner pl(d);
+    std::vector<SliceRec> sl;
+    for (int i = 0; i < ncalls; ++i) {
+        st = pl.feed(n[i], sl);
+        if (st != PV_OK) return st;
+        if (avail) avail[i] = pl.available();
+        pl.retrieve(pl.available());
+    }
+    for (int64_t i = 0; i < (int64_t)sl.size() && i < max_slices; ++i) {
+        if (shift) shift[i] = sl[(size_t)i].shift;
+        if (phase) phase[i] = sl[(size_t)i].phase_inc;
+    }
+    if (nslices) *nslices = (int64_t)sl.size();
+    if (info) fill_info(d, (int64_t)sl.size(), info);
+    return PV_OK;
+}
+
+// ---------------------------------------------------------------- batch
+int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int32_t block, int32_t flush, int device,
+                    pv_batch **out) {
+    if (!cfg || !out || nstreams < 1 || frames < 1 || block < 1) return PV_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::unique_ptr<pv_batch> b(new pv_batch());
+    const int rows = nstreams * cfg->channels;
+    int Tc = 16384 / (rows > 0 ? rows : 1);
+    if (Tc < 16) Tc = 16;
+    if (Tc > 256) Tc = 256;
+    int st = b->core.init(*cfg, device, nstreams, Tc);
+    if (st != PV_OK) return st;
+    Core &c = b->core;
+    st = plan_batch(c.d, frames, block, flush != 0, b->plan);
+    if (st != PV_OK) return st;
+    b->frames = frames;
+    const auto &sl = b->plan.slices;
+    const int64_t T = (int64_t)sl.size();
+    std::vector<int32_t> pinc((size_t)T);
+    std::vector<int64_t> P((size_t)T);
+    for (int64_t t = 0; t < T; ++t) {
+        pinc[(size_t)t] = sl[(size_t)t].phase_inc;
+        P[(size_t)t] = sl[(size_t)t].P;
+    }
+    std::vector<OlaTile> tiles;
+    for (int64_t t0 = 0; t0 < T; t0 += Tc) {
+        pv_batch::Chunk ch;
+        ch.t0 = t0;
+        ch.Tn = (int)((T - t0) < Tc ? (T - t0) : Tc);
+        const int64_t t1 = t0 + ch.Tn;
+        int64_t ka = sl[(size_t)t0].K0;
+        int64_t kb = sl[(size_t)(t1 - 1)].K0 + sl[(size_t)(t1 - 1)].cnt;
+        if (ka > b->plan.out_frames) ka = b->plan.out_frames;
+        if (kb > b->plan.out_frames) kb = b->plan.out_frames;
+        ch.tile_begin = (int)tiles.size();
+        if (kb > ka) {
+            st = c.build_tiles(sl, 0, t1, ka, kb, 0, tiles);
+            if (st != PV_OK) return st;
+        }
+        ch.ntiles = (int)tiles.size() - ch.tile_begin;
+        b->chunks.push_back(ch);
+    }
+    if ((st = b->d_pinc.upload(pinc)) != PV_OK) return st;
+    if ((st = b->d_P.upload(P)) != PV_OK) return st;
+    if ((st = b->d_tiles.upload(tiles)) != PV_OK) return st;
+    *out = b.release();
+    return PV_OK;
+}
+
+void pv_batch_destroy(pv_batch *b) { delete b; }
+
+int64_t pv_batch_out_frames(const pv_batch *b) { return b ? b->plan.out_frames : -1; }
+int64_t pv_batch_slices(const pv_batch *b) { return b ? (int64_t)b->plan.slices.size() : -1; }
+
+int pv_batch_get_info(const pv_batch *b, pv_info *info) {
+    if (!b || !info) return PV_ERR_INVALID_ARG;
+    fill_info(b->core.d, (int64_t)b->plan.slices.size(), info);
+    return PV_OK;
+}
+
+int pv_batch_enable_timing(pv_batch *b, int on) {
+    if (!b) return PV_ERR_INVALID_ARG;
+    b->timing = on != 0;
+    for (int k = 0; k < PV_NUM_KERNELS; ++k) {
+        b->acc_ms[k] = 0;
+        b->acc_n[k] = 0;
+    }
+    b->ev_used = 0;
+    return PV_OK;
+}
+
+int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream) {
+    if (!b || !d_in || !d_out) return PV_ERR_INVALID_ARG;
+    Core &c = b->core;
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIPC(hipSetDevice(c.device));
+    int rc = c.reset_state(st);
+    if (rc != PV_OK) return rc;
+    InAddr ia;
+    ia.in = d_in;
+    ia.stride_c = b->frames;
+    ia.stride_s = b->frames * c.C;
+    ia.mask = ~0ull;
+    ia.len = b->frames;
+    if (b->timing) {
+        // fold the previous run's events first (caller synchronised), then reuse the pool
+        double ms[PV_NUM_KERNELS];
+        int64_t ln[PV_NUM_KERNELS];
+        (void)pv_batch_kernel_times(b, ms, ln);
+        const size_t need = b->chunks.size() * 8;
+        while (b->ev_pool.size() < need) {
+            hipEvent_t e;
+            HIPC(hipEventCreate(&e));
+            b->ev_pool.push_back(e);
+        }
+    }
+    size_t ci = 0;
+    for (const auto &ch : b->chunks) {
+        hipEvent_t *ev = b->timing ? &b->ev_pool[ci * 8] : nullptr;
+        c.launch_chunk(ia, ch.t0, ch.Tn, b->d_pinc.p + ch.t0, b->d_tiles.p + ch.tile_begin, ch.ntiles, b->d_P.p,
+                       d_out, b->plan.out_frames, 0, st, ev);
+        ++ci;
+    }
+    if (b->timing) b->ev_used = b->chunks.size() * 8;
+    HIPC(hipGetLastError());
+    return PV_OK;
+}
+
+int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launches[PV_NUM_KERNELS]) {
+    if (!b) return PV_ERR_INVALID_ARG;
+    // fold finished event pairs into the accumulators
+    const bool robotic = b->core.d.robotic;
+    for (size_t i = 0; i + 8 <= b->ev_used; i += 8) {
+        const auto &ch = b->chunks[i / 8];
+        for (int k = 0; k < PV_NUM_KERNELS; ++k) {
+            if (k == PV_K_PHASE && robotic) continue;
+            if (k == PV_K_OLA_RESAMPLE && ch.ntiles == 0) continue;
+            float t = 0;
+            if (hipEventElapsedTime(&t, b->ev_pool[i + 2 * k], b->ev_pool[i + 2 * k + 1]) == hipSuccess) {
+                b->acc_ms[k] += t;
+                b->acc_n[k] += 1;
+            }
+        }
+    }
+    b->ev_used = 0;
+    for (int k = 0; k < PV_NUM_KERNELS; ++k) {
+        if (ms) ms[k] = b->acc_ms[k];
+        if (launches) launches[k] = b->acc_n[k];
+    }
+    return PV_OK;
+}
+
+// ---------------------------------------------------------------- streaming
+static constexpr int kStreamChunk = 16; // slices per launch group in streaming mode
+
+int pv_create(const pv_config *cfg, int device, pv_engine **out) {
+    if (!cfg || !out) return PV_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::unique_ptr<pv_engine> e(new pv_engine());
+    int st = e->core.init(*cfg, device, 1, kStreamChunk);
+    if (st != PV_OK) return st;
+    Core &c = e->core;
+    e->planner.reset(new Planner(c.d));
+    HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->ring = next_pow2_i(3 * c.d.N + kStreamChunk * c.d.hop + 16);
+    if ((st = e->d_in.alloc((size_t)c.C * e->ring)) != PV_OK) return st;
+    HIPC(hipMemset(e->d_in.p, 0, e->d_in.n * sizeof(float)));
+    if ((st = e->h_in.alloc((size_t)c.C * e->ring)) != PV_OK) return st;
+    // most outputs one group of slices can emit
+    const double per_slice = c.d.resample ? (2.0 * c.d.hop * c.d.hs_ratio) * c.d.res_den / c.d.res_num + 2
+                                          : 2.0 * c.d.hop * c.d.hs_ratio + 2;
+    e->out_cap = (int)(kStreamChunk * per_slice) + 64;
+    if ((st = e->d_out.alloc((size_t)c.C * e->out_cap)) != PV_OK) return st;
+    if ((st = e->h_out.alloc((size_t)c.C * e->out_cap)) != PV_OK) return st;
+    const size_t desc_bytes = 16384;
+    if ((st = e->d_desc.alloc(desc_bytes)) != PV_OK) return st;
+    if ((st = e->h_desc.alloc(desc_bytes)) != PV_OK) return st;
+    e->outq.resize(c.C);
+    *out = e.release();
+    return PV_OK;
+}
+
+void pv_destroy(pv_engine *e) { delete e; }
+
+int32_t pv_available(const pv_engine *e) { return e ? e->planner->available() : -1; }
+
+int pv_get_info(const pv_engine *e, pv_info *info) {
+    if (!e || !info) return PV_ERR_INVALID_ARG;
+    fill_info(e->core.d, e->planner->slices(), info);
+    return PV_OK;
+}
+
+// upload input samples [e->uploaded, upto) of the current call into the device ring
+static int upload_until(pv_engine *e, const float *const *in, int64_t call_base, int64_t upto) {
+    Core &c = e->core;
+    while (e->uploaded < upto) {
+        const int64_t pos = e->uploaded;
+        const int64_t roff = pos & (e->ring - 1);
+        int64_t n = upto - pos;
+        if (n > e->ring - roff) n = e->ring - roff;
+        for (int ch = 0; ch < c.C; ++ch) {
+            float *h = e->h_in.p + (size_t)ch * e->ring + roff;
+            memcpy(h, in[ch] + (pos - call_base), (size_t)n * sizeof(float));
+            HIPC(hipMemcpyAsync(e->d_in.p + (size_t)ch * e->ring + roff, h, (size_t)n * sizeof(float),
+                                hipMemcpyHostToDevice, e->stream));
+        }
+        e->uploaded += n;
+    }
+    return PV_OK;
+}
+
+int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
+    if (!e || n < 0 || (n > 0 && !in)) return PV_ERR_INVALID_ARG;
+    Core &c = e->core;
+    HIPC(hipSetDevice(c.device));
+    const int64_t call_base = e->fed;
+    std::vector<SliceRec> fresh;
+    int st = e->planner->feed(n, fresh);
+    if (st != PV_OK) return st;
+    e->fed += n;
+    const int64_t t_new0 = e->t_base + (int64_t)e->recent.size();
+    e->recent.insert(e->recent.end(), fresh.begin(), fresh.end());
+    const int64_t t_new1 = t_new0 + (int64_t)fresh.size();
+
+    for (int64_t ta = t_new0; ta < t_new1; ta += kStreamChunk) {
+        const int64_t tb = (t_new1 - ta) < kStreamChunk ? t_new1 : ta + kStreamChunk;
+        const int Tn = (int)(tb - ta);
+        // input needed by slices [ta, tb): up to (tb-1)*hop + N.  The pinned staging ring must not be
+        // overwritten while a previous async copy still reads it: groups are synchronised below.
+        int64_t need = (tb - 1) * (int64_t)c.d.hop + c.d.N;
+        if (need > e->fed) need = e->fed;
+        if ((st = upload_until(e, in, call_base, need)) != PV_OK) return st;
+
+        // descriptors: [pinc Tn int32][P list int64][tiles]
+        const SliceRec &first = e->recent[(size_t)(ta - e->t_base)];
+        const SliceRec &last = e->recent[(size_t)(tb - 1 - e->t_base)];
+        const int64_t ka = first.K0, kb = last.K0 + last.cnt;
+        std::vector<OlaTile> tiles;
+        if (kb > ka) {
+            st = c.build_tiles(e->recent, e->t_base, tb, ka, kb, (int32_t)e->t_base, tiles);
+            if (st != PV_OK) return st;
+        }
+        if (kb - ka > e->out_cap) {
+            g_last_error = "internal: streaming output staging too small";
+            return PV_ERR_UNSUPPORTED;
+        }
+        char *hd = e->h_desc.p;
+        size_t off = 0;
+        int32_t *h_pinc = reinterpret_cast<int32_t *>(hd + off);
+        for (int i = 0; i < Tn; ++i) h_pinc[i] = e->recent[(size_t)(ta + i - e->t_base)].phase_inc;
+        off += ((size_t)Tn * 4 + 15) & ~(size_t)15;
+        const size_t p_off_bytes = off;
+        int64_t *h_P = reinterpret_cast<int64_t *>(hd + off);
+        const size_t nP = (size_t)(tb - e->t_base);
+        for (size_t i = 0; i < nP; ++i) h_P[i] = e->recent[i].P;
+        off += (nP * 8 + 15) & ~(size_t)15;
+        const size_t t_off_bytes = off;
+        memcpy(hd + off, tiles.data(), tiles.size() * sizeof(OlaTile));
+        off += tiles.size() * sizeof(OlaTile);
+        if (off > e->h_desc.n) {
+            g_last_error = "internal: descriptor staging too small";
+            return PV_ERR_UNSUPPORTED;
+        }
+        HIPC(hipMemcpyAsync(e->d_desc.p, hd, off, hipMemcpyHostToDevice, e->stream));
+
+        InAddr ia;
+        ia.in = e->d_in.p;
+        ia.stride_c = e->ring;
+        ia.stride_s = (int64_t)e->ring * c.C;
+        ia.mask = (uint64_t)(e->ring - 1);
+        ia.len = INT64_MAX;
+        c.launch_chunk(ia, ta, Tn, reinterpret_cast<const int32_t *>(e->d_desc.p),
+                       reinterpret_cast<const OlaTile *>(e->d_desc.p + t_off_bytes), (int)tiles.size(),
+                       reinterpret_cast<const int64_t *>(e->d_desc.p + p_off_bytes), e->d_out.p, e->out_cap, ka,
+                       e->stream, nullptr);
+        (void)p_off_bytes;
+        const int64_t cnt = kb - ka;
+        if (cnt > 0) {
+            for (int ch = 0; ch < c.C; ++ch)
+                HIPC(hipMemcpyAsync(e->h_out.p + (size_t)ch * e->out_cap, e->d_out.p + (size_t)ch * e->out_cap,
+                                    (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        }
+        HIPC(hipStreamSynchronize(e->stream));
+        HIPC(hipGetLastError());
+        for (int ch = 0; ch < c.C && cnt > 0; ++ch) {
+            const float *src = e->h_out.p + (size_t)ch * e->out_cap;
+            e->outq[(size_t)ch].insert(e->outq[(size_t)ch].end(), src, src + cnt);
+        }
+        // drop slice records no later group can reference
+        const int64_t keep_from = tb - (c.lookback + kStreamChunk + 2);
+        if (keep_from > e->t_base) {
+            e->recent.erase(e->recent.begin(), e->recent.begin() + (size_t)(keep_from - e->t_base));
+            e->t_base = keep_from;
+        }
+    }
+    // everything fed stays needed by later slices (at most 2N unconsumed): park it in the device ring
+    if ((st = upload_until(e, in, call_base, e->fed)) != PV_OK) return st;
+    HIPC(hipStreamSynchronize(e->stream));
+    return PV_OK;
+}
+
+int32_t pv_retrieve(pv_engine *e, float *const *out, int32_t n) {
+    if (!e || n < 0 || (n > 0 && !out)) return -1;
+    const int32_t got = e->planner->retrieve(n);
+    for (int ch = 0; ch < e->core.C; ++ch) {
+        const std::vector<float> &q = e->outq[(size_t)ch];
+        memcpy(out[ch], q.data() + e->outq_head, (size_t)got * sizeof(float));
+    }
+    e->outq_head += (size_t)got;
+    if (e->outq_head > (1u << 16)) {
+        for (auto &q : e->outq) q.erase(q.begin(), q.begin() + (long)e->outq_head);
+        e->outq_head = 0;
+    }
+    return got;
+}
+
+} // extern "C"

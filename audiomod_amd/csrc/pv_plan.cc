@@ -1,0 +1,408 @@
+// pv_plan.cc -- see pv_plan.h.  Host-only; compiled with -ffp-contract=off so the float/double
+// expression shapes below evaluate exactly as written (they are part of the specification:
+// the reference computes these on x86-64 without FMA).
+#include "pv_plan.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace pv {
+
+// ------------------------------------------------------------------------------------------
+// window  (reference dsp/windowfunc.h:159-169: cosine-sum evaluated in double, stored float;
+// area = float running sum / n, :152-156)
+// ------------------------------------------------------------------------------------------
+static void make_hann(int n, std::vector<float> &w, float &area) {
+    w.resize(n);
+    const float a0 = 0.50f, a1 = 0.50f, a2 = 0.0f, a3 = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        float v = 1.0f;
+        double e = (a0 - a1 * std::cos(2 * M_PI * i / n) + a2 * std::cos(4 * M_PI * i / n) -
+                    a3 * std::cos(6 * M_PI * i / n));
+        v = (float)(v * e);
+        w[i] = v;
+    }
+    float acc = 0;
+    for (int i = 0; i < n; ++i) acc += w[i];
+    acc /= n;
+    area = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// FFT plan  (reference kissfft/kiss_fft.c: factor order 4s then 2s :292-316; recursion leaf
+// copy :264-268 gives the input permutation; twiddles in double then float :341-347;
+// kiss_fftr.c:57-63 super twiddles)
+// ------------------------------------------------------------------------------------------
+static void perm_rec(const int *radix, const int *m, const int *fs, int lev, int out_base, int in_base,
+                     std::vector<int32_t> &perm) {
+    if (m[lev] == 1) {
+        for (int q = 0; q < radix[lev]; ++q) perm[out_base + q] = in_base + q * fs[lev];
+    } else {
+        for (int q = 0; q < radix[lev]; ++q)
+            perm_rec(radix, m, fs, lev + 1, out_base + q * m[lev], in_base + q * fs[lev], perm);
+    }
+}
+
+static int make_fft(int nc, FftPlan &p) {
+    p.nc = nc;
+    int radix[kMaxStages], mm[kMaxStages], fs[kMaxStages];
+    int rem = nc, lev = 0, stride = 1;
+    while (rem > 1) {
+        int r = (rem % 4 == 0) ? 4 : 2; // powers of two only: 4s first, a final 2 if log2 is odd
+        if (rem % r) return PV_ERR_INVALID_ARG;
+        rem /= r;
+        if (lev >= kMaxStages) return PV_ERR_INVALID_ARG;
+        radix[lev] = r;
+        mm[lev] = rem;
+        fs[lev] = stride;
+        stride *= r;
+        ++lev;
+    }
+    p.nstages = lev;
+    p.perm.assign(nc, 0);
+    perm_rec(radix, mm, fs, 0, 0, 0, p.perm);
+    for (int s = 0; s < lev; ++s) { // execution order: deepest level first
+        p.radix[s] = radix[lev - 1 - s];
+        p.m[s] = mm[lev - 1 - s];
+        p.fstride[s] = fs[lev - 1 - s];
+    }
+    p.tw_fwd.resize(nc);
+    p.tw_inv.resize(nc);
+    p.st_fwd.resize(nc);
+    p.st_inv.resize(nc);
+    for (int i = 0; i < nc; ++i) {
+        const double pi = 3.141592653589793238462643383279502884197169399375105820974944;
+        double phase = -2 * pi * i / nc;
+        p.tw_fwd[i].r = (float)std::cos(phase);
+        p.tw_fwd[i].i = (float)std::sin(phase);
+        phase *= -1;
+        p.tw_inv[i].r = (float)std::cos(phase);
+        p.tw_inv[i].i = (float)std::sin(phase);
+        double sp = -3.14159265358979323846264338327 * ((double)i / nc + .5);
+        p.st_fwd[i].r = (float)std::cos(sp);
+        p.st_fwd[i].i = (float)std::sin(sp);
+        sp *= -1;
+        p.st_inv[i].r = (float)std::cos(sp);
+        p.st_inv[i].i = (float)std::sin(sp);
+    }
+    return PV_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Speex quality-4 filter design  (reference speex/resample.c: Q4 row of the quality table :290,
+// KAISER8 :233-240 with oversample 32 :262, compute_func :300-322, sinc :325-337,
+// update_filter :661-775)
+// ------------------------------------------------------------------------------------------
+static const double kKaiser8[36] = {
+    0.99635258, 1.00000000, 0.99635258, 0.98548012, 0.96759014, 0.94302200, 0.91223751, 0.87580811, 0.83439927,
+    0.78875245, 0.73966538, 0.68797126, 0.63451750, 0.58014482, 0.52566725, 0.47185369, 0.41941150, 0.36897272,
+    0.32108304, 0.27619388, 0.23465776, 0.19672670, 0.16255380, 0.13219758, 0.10562887, 0.08273982, 0.06335451,
+    0.04724088, 0.03412321, 0.02369490, 0.01563093, 0.00959968, 0.00527363, 0.00233883, 0.00050000, 0.00000000};
+
+static double kaiser8_at(float x) {
+    float y = x * 32;
+    int ind = (int)std::floor(y);
+    float frac = (y - ind);
+    double c3 = -0.1666666667 * frac + 0.1666666667 * (frac * frac * frac);
+    double c2 = frac + 0.5 * (frac * frac) - 0.5 * (frac * frac * frac);
+    double c0 = -0.3333333333 * frac + 0.5 * (frac * frac) - 0.1666666667 * (frac * frac * frac);
+    double c1 = 1.f - c3 - c2 - c0;
+    return c0 * kKaiser8[ind] + c1 * kKaiser8[ind + 1] + c2 * kKaiser8[ind + 2] + c3 * kKaiser8[ind + 3];
+}
+
+static float sinc_tap(float cutoff, float x, int n) {
+    float xx = x * cutoff;
+    if (std::fabs(x) < 1e-6) return cutoff;
+    if (std::fabs(x) > .5 * n) return 0;
+    return (float)(cutoff * std::sin(M_PI * xx) / (M_PI * xx) * kaiser8_at((float)std::fabs(2. * x / n)));
+}
+
+static uint32_t gcd_u32(uint32_t a, uint32_t b) {
+    while (b) {
+        uint32_t t = b;
+        b = a % b;
+        a = t;
+    }
+    return a;
+}
+
+static void make_resampler(Derived &d) {
+    // RS_Speex::setratio (reference dsp/resampler.cc:740-770): ratio -> fraction over 272408136
+    const float ratio = (float)(1.0 / d.pitch_scale); // writeSlice passes 1.0 / m_pitchScale (phasevocoderprocess.cc:1174)
+    d.res_ratio = ratio;
+    const uint32_t big = 272408136U;
+    uint32_t denom = 1, num = 1;
+    if (ratio < 1.f) {
+        denom = big;
+        double dnum = double(big) * double(ratio);
+        num = (uint32_t)dnum;
+    } else if (ratio > 1.f) {
+        num = big;
+        double ddenom = double(big) / double(ratio);
+        denom = (uint32_t)ddenom;
+    }
+    uint32_t num_rate = denom, den_rate = num; // speex_resampler_set_rate_frac(st, denom, num, ...)
+    uint32_t g = gcd_u32(num_rate, den_rate);
+    num_rate /= g;
+    den_rate /= g;
+    d.res_num = num_rate;
+    d.res_den = den_rate;
+    uint32_t oversample = 8, filt_len = 64;
+    float cutoff;
+    if (num_rate > den_rate) {
+        cutoff = 0.921f * den_rate / num_rate;
+        filt_len = (uint32_t)std::ceil(filt_len * ((double)num_rate / (double)den_rate));
+        filt_len &= (~0x3u);
+        if (2 * den_rate < num_rate) oversample >>= 1;
+        if (4 * den_rate < num_rate) oversample >>= 1;
+        if (8 * den_rate < num_rate) oversample >>= 1;
+        if (16 * den_rate < num_rate) oversample >>= 1;
+        if (oversample < 1) oversample = 1;
+    } else {
+        cutoff = 0.940f;
+    }
+    d.filt_len = (int)filt_len;
+    d.oversample = (int)oversample;
+    if (den_rate <= oversample) {
+        d.interp = false;
+        d.sinc.assign((size_t)filt_len * den_rate, 0.f);
+        for (uint32_t i = 0; i < den_rate; i++)
+            for (int j = 0; j < (int)filt_len; j++)
+                d.sinc[i * filt_len + j] =
+                    sinc_tap(cutoff, ((j - (int)filt_len / 2 + 1) - ((float)i) / den_rate), (int)filt_len);
+    } else {
+        d.interp = true;
+        d.sinc.assign((size_t)filt_len * oversample + 8, 0.f);
+        for (int i = -4; i < (int)(oversample * filt_len + 4); i++)
+            d.sinc[i + 4] = sinc_tap(cutoff, (i / (float)oversample - filt_len / 2), (int)filt_len);
+    }
+    d.int_adv = (int)(num_rate / den_rate);
+    d.frac_adv = (int)(num_rate % den_rate);
+}
+
+static size_t next_pow2(size_t v) {
+    if (!(v & (v - 1))) return v;
+    int bits = 0;
+    while (v) {
+        ++bits;
+        v >>= 1;
+    }
+    return (size_t)1 << bits;
+}
+
+int derive(const pv_config &cfg, Derived &d) {
+    d = Derived();
+    d.cfg = cfg;
+    if (cfg.channels < 1 || cfg.channels > 64 || cfg.sample_rate < 1 || cfg.fftsize < 1 || cfg.hopsize < 0)
+        return PV_ERR_INVALID_ARG;
+    switch (cfg.mode) {
+    case PV_MODE_NORMAL_SHIFT:
+    case PV_MODE_GENDER_CHANGE:
+    case PV_MODE_FORMANT_PRESERVE:
+    case PV_MODE_NORMAL_STRETCH:
+    case PV_MODE_ROBOTIC:
+        break;
+    default:
+        return PV_ERR_UNSUPPORTED; // CONSTANT / VOCODER_* / WHISPER are outside the hot path
+    }
+    // phasevocoder.cc:25-26: float semis/12, double pow, stored float
+    d.time_ratio = cfg.time_ratio;
+    d.pitch_scale = cfg.pitch_semitones != 0 ? (float)std::pow(2.0, cfg.pitch_semitones / 12) : 1.0f;
+    d.robotic = cfg.mode == PV_MODE_ROBOTIC;
+
+    size_t windowSize = next_pow2((size_t)cfg.fftsize);
+    if (windowSize < 64 || windowSize > 16384) return PV_ERR_INVALID_ARG;
+    if (d.pitch_scale <= 0.0) d.pitch_scale = 1.0;
+    if (d.time_ratio <= 0.0) d.time_ratio = 1.0;
+    const float hsr = d.time_ratio * d.pitch_scale;
+    d.hs_ratio = hsr;
+    size_t inHop, outHop;
+    if (cfg.hopsize > 0) {
+        inHop = (size_t)cfg.hopsize;
+        outHop = (size_t)int(std::floor(inHop * hsr));
+    } else {
+        float wir = 4.5;
+        if (hsr < 1) {
+            if (hsr == 1.0) wir = 4;
+            else if (d.pitch_scale < 1.0) wir = 4.5;
+            else wir = 6;
+            inHop = (size_t)int(windowSize / wir);
+            outHop = (size_t)int(inHop * hsr);
+        } else {
+            if (hsr == 1.0) wir = 4;
+            else wir = 8;
+            outHop = (size_t)int(windowSize / wir);
+            inHop = (size_t)int(outHop / hsr);
+        }
+    }
+    if (inHop < 1 || inHop > windowSize) return PV_ERR_INVALID_ARG;
+    d.N = (int)windowSize;
+    d.hs = d.N / 2;
+    d.H = d.hs + 1;
+    d.hop = (int)inHop;
+    d.hop_out_nominal = (int)outHop;
+    {
+        size_t ob = (size_t)(hsr > 1 ? windowSize * 16 * hsr : windowSize * 16);
+        size_t buf = 2 * windowSize;
+        d.outbuf_cap = (int)(ob < buf ? buf : ob);
+    }
+    {
+        float efr = hsr;
+        d.int_ratio = std::fabs(efr - std::floor(efr)) <= 0.001; // float abs overload in the reference build
+    }
+    d.resample = d.pitch_scale != 1.0;
+    d.two_pi_hop = 2 * M_PI * (size_t)d.hop;
+    d.inv_n = 1.f / (size_t)d.N;
+
+    // freqCompSlice dispatch (phasevocoderprocess.cc:1006-1022, 824-840)
+    const bool formant = cfg.mode == PV_MODE_FORMANT_PRESERVE, gender = cfg.mode == PV_MODE_GENDER_CHANGE;
+    if (formant && d.pitch_scale != 1.0) {
+        d.do_freq_comp = true;
+        d.freq_comp = d.pitch_scale;
+    }
+    if (gender && d.pitch_scale != 1.0) {
+        d.do_freq_comp = true;
+        d.freq_comp = d.pitch_scale > 1 ? (float)(0.85 * d.pitch_scale) : (float)(1.17 * d.pitch_scale);
+    } else if (gender) {
+        d.do_freq_comp = true;
+        d.freq_comp = (float)0.8;
+    }
+    d.fixed_gain = d.pitch_scale > 1 ? d.pitch_scale : 1 / d.pitch_scale;
+
+    make_hann(d.N, d.window, d.win_area);
+    d.win_gain = (float)(d.win_area * 1.5);
+    if (d.resample) make_resampler(d);
+    int st = make_fft(d.N / 2, d.fft);
+    if (st != PV_OK) return st;
+
+    // smallest shift any slice can take: the clamp lrint(h*ratio/2) (phasevocoderprocess.cc:394-395)
+    if (d.robotic) d.min_shift = d.hop;
+    else if (d.int_ratio) d.min_shift = (int)(size_t)(d.hop * hsr);
+    else d.min_shift = (int)std::lrint(((size_t)d.hop * hsr) / 2);
+    if (d.min_shift < 1) return PV_ERR_INVALID_ARG;
+    return PV_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Planner
+// ------------------------------------------------------------------------------------------
+// calculateThisIncrement (phasevocoderprocess.cc:379-410) + calculateIncrements (:461-487)
+int Planner::next_increment() {
+    const float ratio = d_.hs_ratio;
+    const size_t increment = (size_t)d_.hop;
+    const size_t samplerate = (size_t)d_.cfg.sample_rate;
+    recovery_ = divergence_ / ((samplerate / 10.0) / increment);
+    int incr = (int)std::lrint(increment * ratio - recovery_);
+    if (incr < std::lrint((increment * ratio) / 2)) {
+        incr = (int)std::lrint((increment * ratio) / 2);
+    } else if (incr > std::lrint(increment * ratio * 2)) {
+        incr = (int)std::lrint(increment * ratio * 2);
+    }
+    float divdiff = (increment * ratio) - incr;
+    float prev = divergence_;
+    divergence_ -= divdiff;
+    if ((prev < 0 && divergence_ > 0) || (prev > 0 && divergence_ < 0)) {
+        recovery_ = divergence_ / ((samplerate / 10.0) / increment);
+    }
+    return incr;
+}
+
+int Planner::try_slice(std::vector<SliceRec> &out) {
+    if (in_fill_ < d_.N) return PV_OK; // inbufReady false -> processOneSlice returns early
+    in_fill_ -= d_.hop;
+    size_t phaseInc, shiftInc;
+    if (d_.robotic) {
+        phaseInc = shiftInc = (size_t)d_.hop;
+    } else if (d_.int_ratio) {
+        phaseInc = shiftInc = (size_t)((size_t)d_.hop * d_.hs_ratio);
+    } else {
+        int incr = next_increment();
+        shiftInc = (size_t)incr;
+        phaseInc = prev_increment_ == 0 ? shiftInc : (size_t)prev_increment_;
+        prev_increment_ = (int64_t)shiftInc;
+    }
+    if ((int64_t)shiftInc < 1 || (int64_t)shiftInc > d_.N) return PV_ERR_UNSUPPORTED;
+    SliceRec r;
+    r.shift = (int32_t)shiftInc;
+    r.phase_inc = (int32_t)phaseInc;
+    r.P = P_;
+    r.K0 = K_;
+    const int64_t Pn = P_ + (int64_t)shiftInc;
+    int64_t Kn;
+    if (d_.resample) {
+        // outputs k with filt_len/2 + floor(k*num/den) < Pn  (speex loop condition, resample.c:362,474)
+        int64_t X = Pn - d_.filt_len / 2;
+        if (X <= 0) Kn = 0;
+        else Kn = (int64_t)(((unsigned __int128)X * d_.res_den + d_.res_num - 1) / d_.res_num);
+        // the per-call output cap of RS_Speex::doresample (dsp/resampler.cc:783) must not bind
+        int64_t cap = std::lrintf(std::ceil((float)((int)shiftInc * d_.res_ratio)));
+        if (Kn - K_ > cap) return PV_ERR_UNSUPPORTED;
+    } else {
+        Kn = Pn;
+    }
+    r.cnt = (int32_t)(Kn - K_);
+    // output-ring guard (phasevocoderprocess.cc:337-364)
+    int required = int(shiftInc / d_.pitch_scale) + 1;
+    int64_t ws = d_.outbuf_cap - out_fill_;
+    if (ws < required) return PV_ERR_OUTPUT_OVERRUN;
+    out_fill_ += r.cnt;
+    P_ = Pn;
+    K_ = Kn;
+    ++slices_;
+    out.push_back(r);
+    return PV_OK;
+}
+
+int Planner::feed(int64_t n, std::vector<SliceRec> &out) {
+    if (n < 0) return PV_ERR_INVALID_ARG;
+    int64_t remaining = n;
+    bool allread = false;
+    const int64_t cap = 2 * (int64_t)d_.N; // input ring capacity (channelinfo.cc:31-35)
+    while (!allread) {
+        int64_t w = cap - in_fill_;
+        if (w > remaining) w = remaining;
+        in_fill_ += w;
+        remaining -= w;
+        allread = remaining == 0;
+        int st = try_slice(out);
+        if (st != PV_OK) return st;
+    }
+    return PV_OK;
+}
+
+int plan_batch(const Derived &d, int64_t frames, int block, bool flush, BatchPlan &bp) {
+    if (frames < 0 || block < 1) return PV_ERR_INVALID_ARG;
+    Planner pl(d);
+    bp.slices.clear();
+    int64_t produced = 0, fed = 0;
+    for (int64_t i = 0; i < frames; i += block) {
+        int64_t n = frames - i < block ? frames - i : block;
+        int st = pl.feed(n, bp.slices);
+        if (st != PV_OK) return st;
+        fed += n;
+        produced += pl.retrieve(pl.available());
+    }
+    if (flush) {
+        int guard = 0;
+        while (produced < frames) {
+            int st = pl.feed(block, bp.slices);
+            if (st != PV_OK) return st;
+            fed += block;
+            int32_t got = pl.retrieve(pl.available());
+            produced += (frames - produced > got) ? got : (frames - produced);
+            if (++guard > (1 << 24)) return PV_ERR_UNSUPPORTED;
+        }
+    }
+    bp.out_frames = produced;
+    bp.in_frames = fed;
+    return PV_OK;
+}
+
+int64_t bytes_per_slice(const Derived &d) {
+    // B_slice = 4*(3N + 7H + 2s + h); without resampling 4*(3N + 7H + s)
+    int64_t N = d.N, H = d.H, s = d.hop_out_nominal, h = d.hop;
+    return d.resample ? 4 * (3 * N + 7 * H + 2 * s + h) : 4 * (3 * N + 7 * H + s);
+}
+
+} // namespace pv

@@ -1,0 +1,110 @@
+// pv_plan.h -- host-side, data-independent part of the phase-vocoder engine:
+// derived constants, precomputed tables and the integer "slice scheduler".
+//
+// Everything here is pure host C++ (no HIP), so it is unit-tested on CPU through
+// pv_plan_simulate() (include/audiomod_pv.h).  It restates, from the behaviour documented
+// in SURVEY.md section 8(a), the reference's
+//   - constructor / calculateSizes   (phasevocoder.cc:24-85, phasevocoderimpl.cc:169-263)
+//   - processNormal scheduling loop   (phasevocoderimpl.cc:340-369, phasevocoderprocess.cc:43-64,236-303)
+//   - calculateIncrements             (phasevocoderprocess.cc:379-489)
+//   - Speex rate set-up + filter table(resampler.cc:740-770, speex/resample.c:285-351,661-913,1117-1158)
+//   - kissfft twiddles / factor order (kissfft/kiss_fft.c:292-347, kiss_fftr.c:57-63)
+//   - periodic Hann window            (dsp/windowfunc.h:129-169)
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "audiomod_pv.h"
+
+namespace pv {
+
+struct cpx {
+    float r, i;
+};
+
+constexpr int kMaxStages = 16;
+
+struct FftPlan {
+    int nc = 0;      // complex FFT length = N/2
+    int nstages = 0; // executed innermost first: stage 0 is the deepest recursion level
+    int radix[kMaxStages];
+    int m[kMaxStages];
+    int fstride[kMaxStages];
+    std::vector<int32_t> perm;   // out index -> in index (the recursion's leaf copy)
+    std::vector<cpx> tw_fwd, tw_inv; // nc twiddles each
+    std::vector<cpx> st_fwd, st_inv; // nc "super twiddles" each
+};
+
+struct Derived {
+    pv_config cfg;
+    int N = 0, hs = 0, H = 0, hop = 0, hop_out_nominal = 0;
+    int outbuf_cap = 0; // output ring capacity (frames)
+    float time_ratio = 1, pitch_scale = 1, hs_ratio = 1;
+    bool int_ratio = false, resample = false;
+    bool robotic = false;
+    bool do_freq_comp = false;
+    float freq_comp = 1, fixed_gain = 1;
+    double two_pi_hop = 0; // (2*M_PI)*hop in double, the common factor of omega / pomega / delta_omega
+    float inv_n = 0;       // 1.f / N
+    // window
+    std::vector<float> window;
+    float win_area = 0, win_gain = 0; // gain = float(area * 1.5)
+    // resampler (valid when resample)
+    float res_ratio = 1;
+    uint32_t res_num = 1, res_den = 1; // speex num_rate / den_rate (input step = num/den)
+    int filt_len = 0, oversample = 0, int_adv = 0, frac_adv = 0;
+    bool interp = true;
+    std::vector<float> sinc;
+    FftPlan fft;
+    int min_shift = 1; // lower bound of any shift increment (sizes the frame ring)
+};
+
+// Fills d from cfg.  Returns PV_OK / PV_ERR_INVALID_ARG / PV_ERR_UNSUPPORTED.
+int derive(const pv_config &cfg, Derived &d);
+
+struct SliceRec {
+    int32_t shift;     // shiftIncrement s_t
+    int32_t phase_inc; // phaseIncrement
+    int64_t P;         // OLA-stream position of this slice's frame = sum of previous shifts
+    int64_t K0;        // outputs emitted before this slice
+    int32_t cnt;       // outputs emitted by this slice
+};
+
+// Integer simulation of the reference's ring occupancy and increment recurrences.
+class Planner {
+  public:
+    explicit Planner(const Derived &d) : d_(d) {}
+    // == one processNormal(n) call; appends the slices it runs to `out`.
+    int feed(int64_t n, std::vector<SliceRec> &out);
+    int32_t available() const { return (int32_t)out_fill_; }
+    int32_t retrieve(int32_t n) {
+        int32_t g = n < out_fill_ ? n : (int32_t)out_fill_;
+        if (g < 0) g = 0;
+        out_fill_ -= g;
+        return g;
+    }
+    int64_t slices() const { return slices_; }
+    int64_t outputs() const { return K_; }
+    int64_t ola_len() const { return P_; }
+
+  private:
+    int try_slice(std::vector<SliceRec> &out);
+    int next_increment();
+    const Derived &d_;
+    int64_t in_fill_ = 0, out_fill_ = 0, slices_ = 0, K_ = 0, P_ = 0;
+    float recovery_ = 0, divergence_ = 0;
+    int64_t prev_increment_ = 0;
+};
+
+// Whole-job plan of the batch API: the reference CLI loop (main/main.cc:471-510) with `block`-frame calls.
+struct BatchPlan {
+    std::vector<SliceRec> slices;
+    int64_t out_frames = 0; // frames the CLI would write
+    int64_t in_frames = 0;
+};
+int plan_batch(const Derived &d, int64_t frames, int block, bool flush, BatchPlan &bp);
+
+int64_t bytes_per_slice(const Derived &d);
+
+} // namespace pv

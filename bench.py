@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the phase-vocoder hot path on MI355X (contract: see the task statement).
+
+A "step" is one pass of the whole hot path (analysis FFT -> phase propagation -> synthesis FFT ->
+overlap-add + resample) over one batch of synthetic input that is already resident in HBM:
+STREAMS independent 48 kHz stereo streams of SECONDS seconds each per GPU, BASELINE.json
+configs[1] (normal_pitchshift +4 semitones, phase-locked, fft 2048).  Streams shard one set per
+GPU with no data-path collective (weak scaling: per-GPU work is fixed).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def make_input(torch, streams, frames, device, rank):
+    """Synthetic 48 kHz stereo on the int16 grid: a few host-synthesised voices, varied per stream on the GPU."""
+    from audiomod_amd import signals
+    base_n = min(frames, 10 * 48000)
+    nb = 4
+    base = np.stack([signals.voice(base_n, 2, stream=rank * nb + i) for i in range(nb)])
+    b = torch.from_numpy(base).to(device)
+    reps = (frames + base_n - 1) // base_n
+    x = torch.empty((streams, 2, frames), dtype=torch.float32, device=device)
+    for s in range(streams):
+        v = b[s % nb].repeat(1, reps)[:, :frames]
+        v = torch.roll(v, shifts=(s // nb) * 4099, dims=1) * (1.0 - 0.01 * (s % 7))
+        x[s] = torch.round(v * 32768.0) / 32768.0
+    return x
+
+
+def cpu_baseline(seconds=120):
+    """The real reference (oracle/_ref/ref_driver, kind 'reference') or, where absent, the oracle port,
+    timed on ONE host core on one stereo stream of the same workload."""
+    from audiomod_amd import signals
+    from oracle import oracle_py as O
+    frames = seconds * 48000
+    x = np.tile(signals.voice(10 * 48000, 2), (1, (seconds + 9) // 10))[:, :frames]
+    kw = dict(mode="normal_pitchshift", semitones=4.0, coremode=1, fftsize=2048)
+    if O.have_ref():
+        kind = "reference"
+        with tempfile.TemporaryDirectory() as d:
+            fin = os.path.join(d, "in.f32")
+            x.tofile(fin)
+            cmd = [O.REF_DRIVER, "offline", fin, os.path.join(d, "out.f32"), os.path.join(d, "cnt.txt"), "2",
+                   str(frames), "48000", "1.0", "4.0", "0", "1", "2048", "480", "1"]
+            t0 = time.perf_counter()
+            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dt = time.perf_counter() - t0
+    else:
+        kind = "port"
+        t0 = time.perf_counter()
+        O.run_offline(x, **kw)
+        dt = time.perf_counter() - t0
+    return {"value": round(frames * 2 / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": kind,
+            "x_realtime": round(seconds / dt, 2),
+            "sample": f"1 stereo stream x {seconds} s, same config, block 480, wall {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=128, help="stereo streams per GPU (cfg5: 1024 / 8)")
+    ap.add_argument("--seconds", type=int, default=20, help="audio seconds per stream per step")
+    ap.add_argument("--coremode", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from audiomod_amd import engine as E
+    frames = args.seconds * 48000
+    kw = dict(mode="normal_pitchshift", semitones=4.0, coremode=args.coremode, fftsize=2048)
+    batch = E.Batch(args.streams, frames, channels=2, block=480, flush=True, device=local_rank, **kw)
+    info = batch.info()
+    d_in = make_input(torch, args.streams, frames, device, rank)
+    d_out = batch.alloc_out()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run(d_in, d_out)
+    barrier()
+    batch.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run(d_in, d_out)
+    barrier()
+    dt = time.perf_counter() - t0
+    ktimes = batch.kernel_times()
+    batch.enable_timing(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_streams = args.streams * world
+        ch_samples = total_streams * frames * 2 * args.steps
+        value = ch_samples / dt / 1e6
+        xrt_gpu = args.streams * args.seconds * args.steps / dt
+        slices_per_launch_total = batch.slices * 2 * args.streams  # per step, all chunks
+        N, H, s, h = info["fftsize"], info["fftsize"] // 2 + 1, info["hop_out_nominal"], info["hop_in"]
+        kbytes = {  # algorithmic bytes per slice of each kernel: sums to 4*(3N+7H+2s+h)
+            "pv_analyze_kernel": 4 * (N + 2 * H),
+            "pv_phase_kernel": 4 * (3 * H),
+            "pv_synth_kernel": 4 * (2 * H + N),
+            "pv_ola_kernel": 4 * (N + 2 * s + h),
+        }
+        assert sum(kbytes.values()) == info["bytes_per_slice"]
+        per_kernel = {}
+        for k, (ms, n) in ktimes.items():
+            if n:
+                slices_per_launch = slices_per_launch_total * args.steps / n
+                avg_ms = ms / n
+                per_kernel[k] = {"avg_ms": round(avg_ms, 4), "launches": int(n), "total_ms": round(ms, 2),
+                                 "GBps": round(kbytes[k] * slices_per_launch / (avg_ms * 1e-3) / 1e9, 1)}
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["total_ms"])
+        achieved = per_kernel[dom]["GBps"]
+        pipeline_gbps = info["bytes_per_slice"] * slices_per_launch_total * args.steps / dt / 1e9
+        line = {
+            "metric": "Msamples/s (48 kHz stereo) phase-vocoder pitch-shift; x real-time per GPU",
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "x_realtime_per_gpu": round(xrt_gpu, 1),
+            "config": {"workload": "configs[1]: normal_pitchshift +4 st, stereo 48 kHz, fft=2048, phase-locked"
+                                   if args.coremode == 1 else f"configs[1] with coremode {args.coremode}",
+                       "streams_per_gpu": args.streams, "seconds_per_stream": args.seconds, "channels": 2,
+                       "block": 480, "hop_in": h, "slices_per_channel": int(batch.slices),
+                       "parallelism": f"stream-sharded x{world}, no collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "pipeline_GBps": round(pipeline_gbps, 1), "per_kernel": per_kernel},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,145 @@
+/* audiomod_pv.h -- C ABI of the MI355X-native phase-vocoder engine (libaudiomod_pv.so).
+ *
+ * This is the drop-in boundary for the phase-vocoder hot path of tangkk/audiomod.  The
+ * reference has no C ABI or plugin loader: its callers use the C++
+ * class audiomod::phasevocoder (reference include/dafx/phasevocoder.h:42-117) through
+ * modbase / modbase_offline (reference include/dafx/modbase.h:26-66,75-126).  The entry
+ * points below are what that class binds to underneath (see include/dafx/phasevocoder.h in
+ * this repository for the source-compatible class, and INTEGRATION.md for how a reference
+ * maintainer swaps it in).  Plain pointers and sizes only; no C++ or torch types; no
+ * exceptions cross this boundary -- every call returns a pv_status.
+ *
+ * Semantics: one engine instance == one FRESH reference process.  The reference keeps
+ * DSP state in process-global statics (phasevocoderprocess.cc:380-384,602,716;
+ * phasevocoderimpl.cc:46-62, phasevocoderimpl.h:236-238); here that state is per instance.
+ */
+#ifndef AUDIOMOD_PV_H
+#define AUDIOMOD_PV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* mode / coremode values: reference include/dafx/phasevocoder.h:22-36 */
+#define PV_MODE_CONSTANT (-1)
+#define PV_MODE_NORMAL_SHIFT 0
+#define PV_MODE_GENDER_CHANGE 1
+#define PV_MODE_FORMANT_PRESERVE 2
+#define PV_MODE_VOCODER_ROSENBERG 3
+#define PV_MODE_VOCODER_CHORD 4
+#define PV_MODE_NORMAL_STRETCH 5
+#define PV_MODE_ROBOTIC 6
+#define PV_MODE_WHISPER 7
+#define PV_CORE_NORMAL_PV 0
+#define PV_CORE_PHASE_LOCKED 1
+#define PV_CORE_INT_RATIO 2
+
+typedef enum pv_status {
+    PV_OK = 0,
+    PV_ERR_INVALID_ARG = 1,
+    PV_ERR_UNSUPPORTED = 2,   /* mode outside the hot path (vocoder/constant/whisper), or a resample ratio whose
+                                 per-slice output cap would bind (reference resampler.cc:783) */
+    PV_ERR_NO_DEVICE = 3,     /* no usable MI355X / HIP runtime: the product has NO CPU fallback */
+    PV_ERR_HIP = 4,           /* a HIP call failed; pv_last_error() has the text */
+    PV_ERR_OUTPUT_OVERRUN = 5 /* caller let more than the reference's output ring capacity pile up
+                                 (reference phasevocoderprocess.cc:344-364 drops the slice there) */
+} pv_status;
+
+/* Constructor arguments of audiomod::phasevocoder (reference include/dafx/phasevocoder.h:54). */
+typedef struct pv_config {
+    int32_t sample_rate;
+    int32_t channels;
+    float time_ratio;
+    float pitch_semitones;
+    int32_t mode;     /* PV_MODE_* */
+    int32_t coremode; /* PV_CORE_* */
+    int32_t fftsize;  /* rounded up to a power of two like the reference (phasevocoderimpl.cc:177-181) */
+    int32_t hopsize;  /* 0 = auto, the only value the reference CLI passes */
+} pv_config;
+
+/* Derived constants (reference Impl::calculateSizes, phasevocoderimpl.cc:169-263, and the Speex set-up,
+ * resampler.cc:740-770 + resample.c:661-913). */
+typedef struct pv_info {
+    int32_t fftsize, hop_in, hop_out_nominal, outbuf_capacity;
+    float pitch_scale, hs_ratio;
+    int32_t int_ratio, resample;
+    uint32_t res_num, res_den;
+    int32_t res_filt_len, res_oversample, res_interp;
+    int64_t slices;        /* slices processed so far */
+    int64_t bytes_per_slice; /* algorithmic HBM bytes per slice, SURVEY.md section 8(d): 4*(3N+7H+2s+h) */
+} pv_info;
+
+const char *pv_strerror(int status);
+const char *pv_last_error(void);
+/* number of visible HIP devices that are gfx950; <= 0 means the library cannot run */
+int pv_device_count(void);
+
+/* ----------------------------------------------------------------------------------------------
+ * Host planner only (no GPU needed): the reference's data-independent integer behaviour.
+ * Feeds `ncalls` blocks of sizes n[i] through the scheduling logic of Impl::processNormal
+ * (phasevocoderimpl.cc:340-369), retrieving everything available after each call like the
+ * reference CLI (main/main.cc:484-491); writes the per-call availability to avail[i].  If shift /
+ * phase are non-NULL they receive the per-slice increments of calculateIncrements
+ * (phasevocoderprocess.cc:412-489), up to max_slices; *nslices gets the slice count.
+ * -------------------------------------------------------------------------------------------- */
+int pv_plan_simulate(const pv_config *cfg, const int32_t *n, int32_t ncalls, int32_t *avail, int32_t *shift,
+                     int32_t *phase, int64_t max_slices, int64_t *nslices, pv_info *info);
+
+/* ----------------------------------------------------------------------------------------------
+ * Streaming engine: ONE stream of cfg->channels planar channels, host buffers in and out.
+ * Replaces phasevocodercore::{processNormal, numsamples_available, retrieve}
+ * (reference src/phasevocoder/phasevocoderinterface.h:24-172; phasevocoderimpl.cc:340-369;
+ * phasevocoderprocess.cc:1240-1284), i.e. what audiomod::phasevocoder::processInData /
+ * getOutData / processBlock call (reference src/phasevocoder/phasevocoder.cc:87-183).
+ * -------------------------------------------------------------------------------------------- */
+typedef struct pv_engine pv_engine;
+
+int pv_create(const pv_config *cfg, int device, pv_engine **out);
+void pv_destroy(pv_engine *e);
+/* == processNormal(in, n): in[c] points at n host floats of channel c.  Synchronous. */
+int pv_feed(pv_engine *e, const float *const *in, int32_t n);
+/* == numsamples_available() */
+int32_t pv_available(const pv_engine *e);
+/* == retrieve(out, n): copies min(n, available) frames per channel; returns the count (>= 0) */
+int32_t pv_retrieve(pv_engine *e, float *const *out, int32_t n);
+int pv_get_info(const pv_engine *e, pv_info *info);
+
+/* ----------------------------------------------------------------------------------------------
+ * Batch engine: `nstreams` independent streams of identical configuration and length, input and
+ * output resident in device memory (HBM).  Equivalent, per stream, to driving the reference CLI
+ * loop (main/main.cc:471-510) with `block`-frame calls: flush != 0 -> feed zeros until `frames`
+ * output frames exist and truncate to `frames` (pitch-shift modes); flush == 0 -> no flush
+ * (time_stretch).  This is the throughput path bench.py measures.
+ *   d_in  : [nstreams][channels][frames]      float32, device
+ *   d_out : [nstreams][channels][out_frames]  float32, device (out_frames = pv_batch_out_frames)
+ * pv_batch_run enqueues all work on `hip_stream` (a hipStream_t passed as void*; NULL = the
+ * default stream) and returns without synchronising.
+ * -------------------------------------------------------------------------------------------- */
+typedef struct pv_batch pv_batch;
+
+int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int32_t block, int32_t flush,
+                    int device, pv_batch **out);
+void pv_batch_destroy(pv_batch *b);
+int64_t pv_batch_out_frames(const pv_batch *b);
+int64_t pv_batch_slices(const pv_batch *b); /* slices per channel per stream */
+int pv_batch_get_info(const pv_batch *b, pv_info *info);
+int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream);
+/* Optional per-kernel timing of the NEXT pv_batch_run calls (HIP events on the run's stream).
+ * After synchronising the stream, pv_batch_kernel_times returns, for each of PV_NUM_KERNELS
+ * kernels, the summed device time in ms and the launch count since timing was enabled. */
+#define PV_NUM_KERNELS 4
+#define PV_K_ANALYZE 0
+#define PV_K_PHASE 1
+#define PV_K_SYNTH 2
+#define PV_K_OLA_RESAMPLE 3
+int pv_batch_enable_timing(pv_batch *b, int on);
+int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launches[PV_NUM_KERNELS]);
+const char *pv_kernel_name(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

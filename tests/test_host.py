@@ -1,0 +1,114 @@
+"""CPU-side tests of the product: the C-ABI library loads and exports every declared symbol, the host
+planner (integer scheduling, increments, resampler set-up) agrees with the oracle, and the product
+fails loudly without a GPU.  No compute kernels are launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from audiomod_amd import engine as E
+from oracle import oracle_py as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "audiomod_pv.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(pv_[a-z_]+)\s*\(", hdr))
+    assert len(names) >= 19
+    L = ctypes.CDLL(E.LIB_PATH)
+    for n in sorted(names):
+        assert hasattr(L, n), f"{n} declared in include/audiomod_pv.h but not exported"
+
+
+def test_product_does_not_link_the_oracle():
+    import subprocess
+    out = subprocess.run(["ldd", E.LIB_PATH], capture_output=True, text=True).stdout
+    assert "pv_oracle" not in out and "audiomod_ref" not in out
+    syms = subprocess.run(["nm", "-D", "--defined-only", E.LIB_PATH], capture_output=True, text=True).stdout
+    assert "pvo_" not in syms
+
+
+PLAN_CASES = [
+    ([480] * 200, dict(channels=2, semitones=4.0)),
+    ([480] * 200, dict(channels=1, semitones=4.0)),
+    ([480] * 200, dict(channels=2, semitones=7.0, mode="formant_pitchshift")),
+    ([480] * 200, dict(channels=2, semitones=-7.0, mode="gender_change")),
+    ([480] * 200, dict(channels=2, time_ratio=1.5, mode="time_stretch", fftsize=4096)),
+    ([480] * 200, dict(channels=2, time_ratio=2.0, mode="time_stretch")),
+    ([480] * 200, dict(channels=2, semitones=12.0)),
+    ([480] * 200, dict(channels=2, semitones=-19.0)),
+    ([480] * 200, dict(channels=2, mode="robotic")),
+    ([64] * 1500, dict(channels=2, semitones=4.0)),
+    ([4800, 1, 0, 17, 20000, 480, 0, 0, 5], dict(channels=2, semitones=-3.0)),
+    ([441] * 300, dict(channels=2, semitones=4.0, sample_rate=44100, fftsize=1024)),
+    ([480] * 200, dict(channels=2, semitones=4.0, hopsize=128)),
+]
+
+
+@pytest.mark.parametrize("calls,kw", PLAN_CASES, ids=[str(i) for i in range(len(PLAN_CASES))])
+def test_planner_matches_oracle(calls, kw):
+    avail, shift, phase, info = E.plan_simulate(calls, **kw)
+    ch = kw["channels"]
+    o = O.Oracle(**kw)
+    ref = []
+    for n in calls:
+        got = o.process(np.zeros((ch, n), np.float32))
+        o.retrieve(got)
+        ref.append(got)
+    s, p = o.increments()
+    oi = o.info()
+    assert list(avail) == ref
+    assert np.array_equal(s, shift) and np.array_equal(p, phase)
+    for k in ("fftsize", "hop_in", "hop_out_nominal", "outbuf_capacity", "pitch_scale", "hs_ratio", "int_ratio",
+              "resample", "slices"):
+        assert info[k] == oi[k], k
+    if info["resample"]:
+        for k in ("res_num", "res_den", "res_filt_len", "res_oversample", "res_interp"):
+            assert info[k] == oi[k], k
+
+
+def test_derived_constants_table():
+    """SURVEY.md section 8 table of derived constants."""
+    rows = [
+        (dict(semitones=4.0), 203, 256, (12382188, 9827749), 80),
+        (dict(semitones=7.0), 170, 256, (272408136, 181810613), 96),
+        (dict(semitones=-7.0), 455, 303, (1782457, 2670668), 64),
+    ]
+    for kw, h, oh, frac, fl in rows:
+        _, _, _, info = E.plan_simulate([480], channels=2, **kw)
+        assert (info["hop_in"], info["hop_out_nominal"]) == (h, oh)
+        assert (info["res_num"], info["res_den"]) == frac
+        assert info["res_filt_len"] == fl
+    _, _, _, info = E.plan_simulate([480], channels=2, mode="time_stretch", time_ratio=1.5, fftsize=4096)
+    assert (info["hop_in"], info["hop_out_nominal"], info["resample"]) == (341, 512, 0)
+    assert info["bytes_per_slice"] == 108572
+    _, _, _, info = E.plan_simulate([480], channels=2, semitones=4.0)
+    assert info["bytes_per_slice"] == 56136
+
+
+def test_first_calls_availability_sequence():
+    """block 480, +4 st: 0,0,0,0,172,203,203,204,..."""
+    avail, _, _, _ = E.plan_simulate([480] * 12, channels=2, semitones=4.0)
+    assert list(avail[:8]) == [0, 0, 0, 0, 172, 203, 203, 204]
+
+
+def test_errors():
+    with pytest.raises(E.PvError):
+        E.plan_simulate([480], channels=0, semitones=4.0)
+    with pytest.raises(E.PvError):
+        E.plan_simulate([480], channels=2, mode="whisper")
+    with pytest.raises(E.PvError):  # output never retrieved: the reference's ring would overrun
+        E.plan_simulate([100000], channels=2, semitones=-3.0)
+
+
+def test_fails_loudly_without_gpu():
+    if E.lib().pv_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(E.PvError, match="no gfx950"):
+        E.PhaseVocoder(48000, 2, 1.0, 4.0)
+    with pytest.raises(E.PvError, match="no gfx950"):
+        E.Batch(2, 48000, semitones=4.0)
