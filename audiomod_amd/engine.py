@@ -56,6 +56,14 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise PvError(f"{LIB_PATH} not built: run `make` (or __graft_entry__.build()); there is no fallback path")
+    # PyTorch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one process
+    # cannot both own the GPU.  Loading torch first makes our DT_NEEDED libamdhip64.so.7 resolve to the copy
+    # torch already mapped, so tensors and our kernels share one runtime.  Without torch (e.g. the C++
+    # drop-in) the library uses /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     fpp = C.POINTER(C.POINTER(C.c_float))
     L.pv_strerror.restype = C.c_char_p
