@@ -557,12 +557,11 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
     ia.stride_s = b->frames * c.C;
     ia.mask = ~0ull;
     ia.len = b->frames;
+    size_t ev_base = 0;
     if (b->timing) {
-        // fold the previous run's events first (caller synchronised), then reuse the pool
-        double ms[PV_NUM_KERNELS];
-        int64_t ln[PV_NUM_KERNELS];
-        (void)pv_batch_kernel_times(b, ms, ln);
-        const size_t need = b->chunks.size() * 8;
+        // each timed run takes a fresh segment of the event pool; pv_batch_kernel_times folds and resets
+        ev_base = b->ev_used;
+        const size_t need = ev_base + b->chunks.size() * 8;
         while (b->ev_pool.size() < need) {
             hipEvent_t e;
             HIPC(hipEventCreate(&e));
@@ -571,12 +570,12 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
     }
     size_t ci = 0;
     for (const auto &ch : b->chunks) {
-        hipEvent_t *ev = b->timing ? &b->ev_pool[ci * 8] : nullptr;
+        hipEvent_t *ev = b->timing ? &b->ev_pool[ev_base + ci * 8] : nullptr;
         c.launch_chunk(ia, ch.t0, ch.Tn, b->d_pinc.p + ch.t0, b->d_tiles.p + ch.tile_begin, ch.ntiles, b->d_P.p,
                        d_out, b->plan.out_frames, 0, st, ev);
         ++ci;
     }
-    if (b->timing) b->ev_used = b->chunks.size() * 8;
+    if (b->timing) b->ev_used = ev_base + b->chunks.size() * 8;
     HIPC(hipGetLastError());
     return PV_OK;
 }
@@ -586,7 +585,7 @@ int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launch
     // fold finished event pairs into the accumulators
     const bool robotic = b->core.d.robotic;
     for (size_t i = 0; i + 8 <= b->ev_used; i += 8) {
-        const auto &ch = b->chunks[i / 8];
+        const auto &ch = b->chunks[(i / 8) % b->chunks.size()];
         for (int k = 0; k < PV_NUM_KERNELS; ++k) {
             if (k == PV_K_PHASE && robotic) continue;
             if (k == PV_K_OLA_RESAMPLE && ch.ntiles == 0) continue;
