@@ -100,14 +100,19 @@ template <typename T> struct PinBuf {
 struct Core {
     Derived d;
     int device = 0, S = 0, C = 0, rows = 0;
-    int Tc = 0, FR = 0, HP = 0, pkmax = 0, lookback = 0;
+    int Tc = 0, TR = 0, FR = 0, HP = 0, pkmax = 0, PKP = 0, lookback = 0;
     int ola_lds_floats = 0;
     DevTables tb{};
     DevBuf<int32_t> perm, iperm;
     DevBuf<float2> tw_fwd, tw_inv, st_fwd, st_inv;
     DevBuf<float> window, sinc;
-    DevBuf<float> mag, phase, frames, st_prev_phase, st_prev_out;
-    DevBuf<int32_t> st_peaks, st_npeaks;
+    DevBuf<float> mag, phase, outphase, frames, rot;
+    DevBuf<uint16_t> peaks;
+    DevBuf<int32_t> npk, modes;
+    DevBuf<PeakRec> recs;
+    // persistent per-row phase state
+    DevBuf<float> st_pp, st_po, st_rot;
+    DevBuf<int32_t> st_kind;
 
     int init(const pv_config &cfg, int dev, int nstreams, int chunk_slices);
     int reset_state(hipStream_t st);
@@ -116,7 +121,7 @@ struct Core {
                     int32_t p_index_base, std::vector<OlaTile> &tiles) const;
     void launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
                       int ntiles, const int64_t *d_P, float *out, int64_t out_stride_row, int64_t k_base,
-                      hipStream_t st, hipEvent_t *ev /* 8 events or null */) const;
+                      hipStream_t st, hipEvent_t *ev /* 2*PV_NUM_KERNELS events or null */) const;
 };
 
 int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
@@ -145,10 +150,7 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     rows = S * C;
     HP = d.hs + 8; // row pitch of the mag / phase planes (16-byte aligned rows)
     pkmax = d.hs / 3 + 2;
-    if (phase_lds_bytes(d.hs, C, pkmax) > 160 * 1024 - 256) {
-        g_last_error = "channels x fftsize exceeds the phase kernel's LDS budget";
-        return PV_ERR_UNSUPPORTED;
-    }
+    PKP = (pkmax + 7) & ~7;
     // frames that can overlap one OLA tile / that must stay in the ring behind the newest slice
     const double step = d.resample ? (double)d.res_num / (double)d.res_den : 1.0;
     const int tile_span = (int)(kTileOut * step) + (d.resample ? d.filt_len : 0) + 4;
@@ -159,6 +161,7 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
         return PV_ERR_UNSUPPORTED;
     }
     Tc = chunk_slices;
+    TR = Tc + 1; // slice-indexed planes keep the last slice of the previous launch (pv_kernels.h)
     FR = next_pow2_i(Tc + lookback + 1);
 
     // tables
@@ -198,20 +201,32 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     tb.st_inv = st_inv.p;
     tb.window = window.p;
 
-    if ((st = mag.alloc((size_t)rows * Tc * HP)) != PV_OK) return st;
-    if ((st = phase.alloc((size_t)rows * Tc * HP)) != PV_OK) return st;
+    const int cm = d.cfg.coremode;
+    const size_t planes = (size_t)rows * TR;
+    if ((st = mag.alloc(planes * HP)) != PV_OK) return st;
+    if ((st = phase.alloc(planes * HP)) != PV_OK) return st;
     if ((st = frames.alloc((size_t)rows * FR * d.N)) != PV_OK) return st;
-    if ((st = st_prev_phase.alloc((size_t)rows * d.hs)) != PV_OK) return st;
-    if ((st = st_prev_out.alloc((size_t)rows * d.hs)) != PV_OK) return st;
-    if ((st = st_peaks.alloc((size_t)S * pkmax)) != PV_OK) return st;
-    if ((st = st_npeaks.alloc((size_t)S)) != PV_OK) return st;
+    if (!d.robotic && cm != 2) {
+        if ((st = outphase.alloc(planes * HP)) != PV_OK) return st;
+        if ((st = st_po.alloc((size_t)rows * d.hs)) != PV_OK) return st;
+        if ((st = st_pp.alloc((size_t)rows * d.hs)) != PV_OK) return st;
+    }
+    if (!d.robotic && cm == 1) {
+        if ((st = peaks.alloc(planes * PKP)) != PV_OK) return st;
+        if ((st = npk.alloc(planes)) != PV_OK) return st;
+        if ((st = modes.alloc(planes)) != PV_OK) return st;
+        if ((st = recs.alloc(planes * PKP)) != PV_OK) return st;
+        if ((st = rot.alloc(planes * PKP)) != PV_OK) return st;
+        if ((st = st_rot.alloc((size_t)rows * PKP)) != PV_OK) return st;
+        if ((st = st_kind.alloc((size_t)rows)) != PV_OK) return st;
+    }
     return reset_state(nullptr);
 }
 
 int Core::reset_state(hipStream_t st) {
-    HIPC(hipMemsetAsync(st_prev_phase.p, 0, st_prev_phase.n * sizeof(float), st));
-    HIPC(hipMemsetAsync(st_prev_out.p, 0, st_prev_out.n * sizeof(float), st));
-    HIPC(hipMemsetAsync(st_npeaks.p, 0, st_npeaks.n * sizeof(int32_t), st));
+    if (st_pp.p) HIPC(hipMemsetAsync(st_pp.p, 0, st_pp.n * sizeof(float), st));
+    if (st_po.p) HIPC(hipMemsetAsync(st_po.p, 0, st_po.n * sizeof(float), st));
+    if (st_kind.p) HIPC(hipMemsetAsync(st_kind.p, 0, st_kind.n * sizeof(int32_t), st));
     return PV_OK;
 }
 
@@ -266,65 +281,127 @@ int Core::build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64
 void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
                         int ntiles, const int64_t *d_P, float *out, int64_t out_stride_row, int64_t k_base,
                         hipStream_t st, hipEvent_t *ev) const {
+    const int cm = d.robotic ? -1 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
+    auto rec = [&](int i) {
+        if (ev) (void)hipEventRecord(ev[i], st);
+    };
     AnalyzeArgs aa{};
     aa.tb = tb;
     aa.ia = ia;
     aa.hop = d.hop;
     aa.t0 = t0;
     aa.Tn = Tn;
-    aa.Tc = Tc;
+    aa.TR = TR;
     aa.rows = rows;
+    aa.PKP = PKP;
+    aa.find_peaks = cm == 1 ? 1 : 0;
     aa.mag = mag.p;
     aa.phase = phase.p;
-    if (ev) (void)hipEventRecord(ev[0], st);
+    aa.peaks = peaks.p;
+    aa.npk = npk.p;
+    rec(2 * PV_K_ANALYZE);
     launch_analyze(aa, st);
-    if (ev) (void)hipEventRecord(ev[1], st);
+    rec(2 * PV_K_ANALYZE + 1);
 
-    if (!d.robotic) {
-        PhaseArgs pa{};
+    if (cm == 1) {
+        MatchArgs ma{};
+        ma.N = d.N;
+        ma.hs = d.hs;
+        ma.HP = HP;
+        ma.PKP = PKP;
+        ma.C = C;
+        ma.hop = d.hop;
+        ma.TR = TR;
+        ma.rows = rows;
+        ma.Tn = Tn;
+        ma.two_pi_hop = d.two_pi_hop;
+        ma.t0 = t0;
+        ma.phase_inc = d_pinc;
+        ma.phase = phase.p;
+        ma.peaks = peaks.p;
+        ma.npk = npk.p;
+        ma.recs = recs.p;
+        ma.modes = modes.p;
+        rec(2 * PV_K_MATCH);
+        launch_match(ma, st);
+        rec(2 * PV_K_MATCH + 1);
+        SeqArgs qa{};
+        qa.N = d.N;
+        qa.hs = d.hs;
+        qa.HP = HP;
+        qa.PKP = PKP;
+        qa.C = C;
+        qa.hop = d.hop;
+        qa.TR = TR;
+        qa.rows = rows;
+        qa.Tn = Tn;
+        qa.two_pi_hop = d.two_pi_hop;
+        qa.t0 = t0;
+        qa.phase_inc = d_pinc;
+        qa.phase = phase.p;
+        qa.peaks = peaks.p;
+        qa.npk = npk.p;
+        qa.recs = recs.p;
+        qa.modes = modes.p;
+        qa.rot = rot.p;
+        qa.outphase = outphase.p;
+        qa.st_kind = st_kind.p;
+        qa.st_rot = st_rot.p;
+        qa.st_po = st_po.p;
+        rec(2 * PV_K_SEQ);
+        launch_seq(qa, st);
+        rec(2 * PV_K_SEQ + 1);
+    } else if (cm == 0) {
+        PropArgs pa{};
         pa.N = d.N;
         pa.hs = d.hs;
         pa.HP = HP;
         pa.C = C;
         pa.hop = d.hop;
-        pa.coremode = (d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0;
+        pa.TR = TR;
+        pa.rows = rows;
+        pa.Tn = Tn;
         pa.two_pi_hop = d.two_pi_hop;
         pa.t0 = t0;
-        pa.Tn = Tn;
-        pa.Tc = Tc;
         pa.phase_inc = d_pinc;
-        pa.mag = mag.p;
         pa.phase = phase.p;
-        pa.st_prev_phase = st_prev_phase.p;
-        pa.st_prev_out = st_prev_out.p;
-        pa.st_peaks = st_peaks.p;
-        pa.st_npeaks = st_npeaks.p;
-        pa.pkmax = pkmax;
-        if (ev) (void)hipEventRecord(ev[2], st);
-        launch_phase(pa, S, st);
-        if (ev) (void)hipEventRecord(ev[3], st);
+        pa.outphase = outphase.p;
+        pa.st_pp = st_pp.p;
+        pa.st_po = st_po.p;
+        rec(2 * PV_K_PROP);
+        launch_prop(pa, st);
+        rec(2 * PV_K_PROP + 1);
     }
 
     SynthArgs sa{};
     sa.tb = tb;
     sa.hop = d.hop;
+    sa.C = C;
     sa.two_pi_hop = d.two_pi_hop;
     sa.do_freq_comp = d.do_freq_comp ? 1 : 0;
     sa.freq_comp = d.freq_comp;
     sa.fixed_gain = d.fixed_gain;
     sa.inv_n = d.inv_n;
     sa.robotic = d.robotic ? 1 : 0;
+    sa.coremode = cm < 0 ? 0 : cm;
     sa.t0 = t0;
     sa.Tn = Tn;
-    sa.Tc = Tc;
+    sa.TR = TR;
     sa.rows = rows;
+    sa.PKP = PKP;
+    sa.phase_inc = d_pinc;
     sa.mag = mag.p;
     sa.phase = phase.p;
+    sa.outphase = outphase.p;
+    sa.peaks = peaks.p;
+    sa.npk = npk.p;
+    sa.modes = modes.p;
+    sa.rot = rot.p;
     sa.frames = frames.p;
     sa.FR = FR;
-    if (ev) (void)hipEventRecord(ev[4], st);
+    rec(2 * PV_K_SYNTH);
     launch_synth(sa, st);
-    if (ev) (void)hipEventRecord(ev[5], st);
+    rec(2 * PV_K_SYNTH + 1);
 
     if (ntiles > 0) {
         OlaArgs oa{};
@@ -349,9 +426,9 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         oa.out = out;
         oa.out_stride_row = out_stride_row;
         oa.k_base = k_base;
-        if (ev) (void)hipEventRecord(ev[6], st);
+        rec(2 * PV_K_OLA_RESAMPLE);
         launch_ola(oa, st);
-        if (ev) (void)hipEventRecord(ev[7], st);
+        rec(2 * PV_K_OLA_RESAMPLE + 1);
     }
 }
 
@@ -383,6 +460,8 @@ using namespace pv;
 // ------------------------------------------------------------------------------------------
 // batch engine
 // ------------------------------------------------------------------------------------------
+static constexpr size_t kEvPerChunk = 2 * PV_NUM_KERNELS;
+
 struct pv_batch {
     Core core;
     BatchPlan plan;
@@ -397,10 +476,10 @@ struct pv_batch {
     DevBuf<int64_t> d_P;
     DevBuf<OlaTile> d_tiles;
     bool timing = false;
-    std::vector<hipEvent_t> ev_pool; // 8 per chunk when timing
+    std::vector<hipEvent_t> ev_pool; // kEvPerChunk per chunk when timing
     size_t ev_used = 0;
-    double acc_ms[PV_NUM_KERNELS] = {0, 0, 0, 0};
-    int64_t acc_n[PV_NUM_KERNELS] = {0, 0, 0, 0};
+    double acc_ms[PV_NUM_KERNELS] = {};
+    int64_t acc_n[PV_NUM_KERNELS] = {};
     ~pv_batch() {
         for (auto e : ev_pool) (void)hipEventDestroy(e);
     }
@@ -445,8 +524,8 @@ const char *pv_last_error(void) { return g_last_error.c_str(); }
 int pv_device_count(void) { return count_gfx950(); }
 
 const char *pv_kernel_name(int k) {
-    static const char *n[PV_NUM_KERNELS] = {"pv_analyze_kernel", "pv_phase_kernel", "pv_synth_kernel",
-                                            "pv_ola_kernel"};
+    static const char *n[PV_NUM_KERNELS] = {"pv_analyze_kernel", "pv_match_kernel", "pv_seq_kernel",
+                                            "pv_prop_kernel",    "pv_synth_kernel", "pv_ola_kernel"};
     return (k >= 0 && k < PV_NUM_KERNELS) ? n[k] : "";
 }
 
@@ -561,7 +640,7 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
     if (b->timing) {
         // each timed run takes a fresh segment of the event pool; pv_batch_kernel_times folds and resets
         ev_base = b->ev_used;
-        const size_t need = ev_base + b->chunks.size() * 8;
+        const size_t need = ev_base + b->chunks.size() * kEvPerChunk;
         while (b->ev_pool.size() < need) {
             hipEvent_t e;
             HIPC(hipEventCreate(&e));
@@ -570,12 +649,12 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
     }
     size_t ci = 0;
     for (const auto &ch : b->chunks) {
-        hipEvent_t *ev = b->timing ? &b->ev_pool[ev_base + ci * 8] : nullptr;
+        hipEvent_t *ev = b->timing ? &b->ev_pool[ev_base + ci * kEvPerChunk] : nullptr;
         c.launch_chunk(ia, ch.t0, ch.Tn, b->d_pinc.p + ch.t0, b->d_tiles.p + ch.tile_begin, ch.ntiles, b->d_P.p,
                        d_out, b->plan.out_frames, 0, st, ev);
         ++ci;
     }
-    if (b->timing) b->ev_used = ev_base + b->chunks.size() * 8;
+    if (b->timing) b->ev_used = ev_base + b->chunks.size() * kEvPerChunk;
     HIPC(hipGetLastError());
     return PV_OK;
 }
@@ -583,11 +662,13 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
 int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launches[PV_NUM_KERNELS]) {
     if (!b) return PV_ERR_INVALID_ARG;
     // fold finished event pairs into the accumulators
-    const bool robotic = b->core.d.robotic;
-    for (size_t i = 0; i + 8 <= b->ev_used; i += 8) {
-        const auto &ch = b->chunks[(i / 8) % b->chunks.size()];
+    const Derived &d = b->core.d;
+    const int cm = d.robotic ? -1 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
+    for (size_t i = 0; i + kEvPerChunk <= b->ev_used; i += kEvPerChunk) {
+        const auto &ch = b->chunks[(i / kEvPerChunk) % b->chunks.size()];
         for (int k = 0; k < PV_NUM_KERNELS; ++k) {
-            if (k == PV_K_PHASE && robotic) continue;
+            if ((k == PV_K_MATCH || k == PV_K_SEQ) && cm != 1) continue;
+            if (k == PV_K_PROP && cm != 0) continue;
             if (k == PV_K_OLA_RESAMPLE && ch.ntiles == 0) continue;
             float t = 0;
             if (hipEventElapsedTime(&t, b->ev_pool[i + 2 * k], b->ev_pool[i + 2 * k + 1]) == hipSuccess) {

@@ -31,45 +31,95 @@ struct InAddr {
     int64_t len;
 };
 
+// Slice-indexed planes (mag, phase, peaks, ...) are rings of TR = Tc + 1 slots per (stream, channel) row:
+// slot(t) = t % TR, so the last slice of the previous launch stays readable (the phase recurrences look
+// one slice back).
+enum : int { kModeInit = 0, kModeProp = 1, kModeLock = 2 };
+
 struct AnalyzeArgs {
     DevTables tb;
     InAddr ia;
     int hop;
-    int64_t t0;  // first slice of this launch
-    int Tn;      // slices in this launch
-    int Tc;      // slice pitch of the mag/phase buffers
-    int rows;    // S*C
-    float *mag;  // [rows][Tc][HP]
-    float *phase;
+    int64_t t0; // first slice of this launch
+    int Tn;     // slices in this launch
+    int TR;     // ring slots
+    int rows;   // S*C
+    int PKP;    // pitch of the peak lists
+    int find_peaks;
+    float *mag;      // [rows][TR][HP]
+    float *phase;    // [rows][TR][HP] analysis phase
+    uint16_t *peaks; // [rows][TR][PKP]
+    int32_t *npk;    // [rows][TR]
 };
 
-struct PhaseArgs {
-    int N, hs, HP, C, hop, coremode;
+// what the sequential kernel needs for one spectral peak of a phase-locked step
+struct PeakRec {
+    float adv;     // (peak_delta_phi * phaseIncrement) / hop
+    float a2;      // analysis phase at the peak bin
+    float a1;      // previous analysis phase (same channel) at the matched previous peak bin
+    uint32_t p1r1; // p1 | (region index of p1 in the previous same-channel step) << 16
+};
+
+struct MatchArgs {
+    int N, hs, HP, PKP, C, hop, TR, rows, Tn;
     double two_pi_hop;
     int64_t t0;
-    int Tn, Tc;
-    const int32_t *phase_inc; // [Tn] phaseIncrement of each slice of this launch
-    float *mag;               // [S*C][Tc][HP]
-    float *phase;             // in: analysis phase, out: synthesis phase (in place)
-    // persistent per-stream state (global memory, loaded to LDS at kernel start, stored at end)
-    float *st_prev_phase; // [S][C][hs]
-    float *st_prev_out;   // [S][C][hs]
-    int32_t *st_peaks;    // [S][pkmax]
-    int32_t *st_npeaks;   // [S]
-    int pkmax;
+    const int32_t *phase_inc; // [Tn]
+    const float *phase;
+    const uint16_t *peaks;
+    const int32_t *npk;
+    PeakRec *recs;  // [rows][TR][PKP]
+    int32_t *modes; // [rows][TR]
+};
+
+struct SeqArgs {
+    int N, hs, HP, PKP, C, hop, TR, rows, Tn;
+    double two_pi_hop;
+    int64_t t0;
+    const int32_t *phase_inc;
+    const float *phase;
+    const uint16_t *peaks;
+    const int32_t *npk;
+    const PeakRec *recs;
+    const int32_t *modes;
+    float *rot;      // [rows][TR][PKP] rotation of each peak region (LOCK steps)
+    float *outphase; // [rows][TR][HP]  per-bin output phase (INIT / PROP steps)
+    // persistent per-row state
+    int32_t *st_kind; // [rows] 0 = zero state, 1 = po_full valid, 2 = lazily locked (st_rot valid)
+    float *st_rot;    // [rows][PKP]
+    float *st_po;     // [rows][hs]
+};
+
+// coremode 0: per-bin recurrence, one thread per bin, streaming over the slices of the launch
+struct PropArgs {
+    int N, hs, HP, C, hop, TR, rows, Tn;
+    double two_pi_hop;
+    int64_t t0;
+    const int32_t *phase_inc;
+    const float *phase;
+    float *outphase;
+    float *st_pp; // [rows][hs]
+    float *st_po; // [rows][hs]
 };
 
 struct SynthArgs {
     DevTables tb;
-    int hop;
+    int hop, C;
     double two_pi_hop;
     int do_freq_comp;
     float freq_comp, fixed_gain, inv_n;
     int robotic;
+    int coremode; // 0: phases from outphase; 1: per-step mode (rot / outphase); 2: phase * inc / hop
     int64_t t0;
-    int Tn, Tc, rows;
+    int Tn, TR, rows, PKP;
+    const int32_t *phase_inc;
     const float *mag;
     const float *phase;
+    const float *outphase;
+    const uint16_t *peaks;
+    const int32_t *npk;
+    const int32_t *modes;
+    const float *rot;
     float *frames; // [rows][FR][N] ring of windowed synthesis frames
     int FR;        // power of two
 };
@@ -108,10 +158,10 @@ struct OlaArgs {
 };
 
 void launch_analyze(const AnalyzeArgs &a, hipStream_t st);
-void launch_phase(const PhaseArgs &a, int nstreams, hipStream_t st);
+void launch_match(const MatchArgs &a, hipStream_t st);
+void launch_seq(const SeqArgs &a, hipStream_t st);
+void launch_prop(const PropArgs &a, hipStream_t st);
 void launch_synth(const SynthArgs &a, hipStream_t st);
 void launch_ola(const OlaArgs &a, hipStream_t st);
-size_t phase_lds_bytes(int hs, int C, int pkmax);
-int phase_threads(int hs);
 
 } // namespace pv

@@ -1,11 +1,15 @@
 // pv_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the phase-vocoder engine.
 //
-// Four kernels, one per HBM-visible stage of SURVEY.md section 8(d):
+// Kernels (the HBM-visible stages of SURVEY.md section 8(d); the phase stage is split three ways):
 //   pv_analyze_kernel : window -> fftshift -> real FFT (LDS butterflies) -> (mag, phase)
 //                       replaces analyzeSlice + FFT::forwardPolar + kiss_fftr
 //                       (reference phasevocoderprocess.cc:492-503, FFT.cc:2617-2631, kiss_fftr.c:67-121)
-//   pv_phase_kernel   : per-stream sequential phase propagation (simple / phase-locked / int-ratio)
-//                       replaces modifySlice{Simple,PhaseLocked,IntRatio} (phasevocoderprocess.cc:558-753)
+//                       + spectral peak picking of modifySlicePhaseLocked (:587-596)
+//   pv_match_kernel   : phase-locked mode, parallel part: peak matching and everything about a peak's
+//                       rotation that does not depend on the recurrence (:640-663)
+//   pv_seq_kernel     : phase-locked mode, sequential part: the per-peak rotation chain, one workgroup
+//                       per (stream, channel) row (:664-665); per-bin INIT / no-peak steps (:606-636)
+//   pv_prop_kernel    : coremode 0, per-bin recurrence of modifySliceSimple (:708-753)
 //   pv_synth_kernel   : freqComp gather -> mag/N * (cosf, sinf) -> inverse real FFT -> ifftshift * window
 //                       replaces freqCompSlice + synthesiseSlice + FFT::inversePolar + kiss_fftri
 //                       (phasevocoderprocess.cc:842-923,1001-1075, FFT.cc:2711-2721, kiss_fftr.c:123-159)
@@ -100,16 +104,27 @@ __device__ __forceinline__ void fft_stages(float2 *buf, const DevTables &tb, con
 }
 
 // --------------------------------------------------------------------------------------------
-// analysis
+// analysis (+ spectral peak picking for the phase-locked mode)
 // --------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_peak(const float *smag, int b, int hs) {
+    // modifySlicePhaseLocked (:587-596): strict local maximum over +-2 bins, b in [2, hs-3]
+    if (b < 2 || b + 2 >= hs) return false;
+    const float mb = smag[b];
+    return mb > smag[b - 1] && mb > smag[b - 2] && mb > smag[b + 1] && mb > smag[b + 2];
+}
+
 __global__ __launch_bounds__(kFftThreads) void pv_analyze_kernel(const AnalyzeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float2 *buf = reinterpret_cast<float2 *>(smem_raw);
-    int row, tl;
-    if (!block_to_row_slice(a.Tn, a.rows, row, tl)) return;
     const DevTables &tb = a.tb;
     const int N = tb.N, hs = tb.hs, nc = tb.nc, nt = blockDim.x;
-    const int64_t a0 = (a.t0 + tl) * (int64_t)a.hop;
+    float2 *buf = reinterpret_cast<float2 *>(smem_raw); // [nc]
+    float *smag = reinterpret_cast<float *>(buf + nc);  // [hs + 1]
+    int *wcnt = reinterpret_cast<int *>(smag + hs + 4); // [(hs/nt + 1) * 4]
+    int row, tl;
+    if (!block_to_row_slice(a.Tn, a.rows, row, tl)) return;
+    const int64_t t = a.t0 + tl;
+    const int slot = (int)(t % a.TR);
+    const int64_t a0 = t * (int64_t)a.hop;
     // row = s*Cch + c; the host guarantees stride_s == Cch*stride_c for contiguous rows
     const float *__restrict__ in = a.ia.in + (int64_t)row * a.ia.stride_c;
     const float *__restrict__ w = tb.window;
@@ -127,15 +142,19 @@ __global__ __launch_bounds__(kFftThreads) void pv_analyze_kernel(const AnalyzeAr
     fft_stages<false>(buf, tb, tb.tw_fwd);
 
     // real-FFT split (kiss_fftr.c:91-120) + polar (FFT.cc:2623-2630)
-    float *__restrict__ mag = a.mag + ((int64_t)row * a.Tc + tl) * tb.HP;
-    float *__restrict__ ph = a.phase + ((int64_t)row * a.Tc + tl) * tb.HP;
+    const int64_t plane = ((int64_t)row * a.TR + slot);
+    float *__restrict__ mag = a.mag + plane * tb.HP;
+    float *__restrict__ ph = a.phase + plane * tb.HP;
     for (int k = threadIdx.x; k <= nc / 2; k += nt) {
         if (k == 0) {
             const float2 tdc = buf[0];
             const float r0 = tdc.x + tdc.y, rn = tdc.x - tdc.y;
-            mag[0] = sqrtf(r0 * r0 + 0.f * 0.f);
+            const float m0 = sqrtf(r0 * r0 + 0.f * 0.f), mn = sqrtf(rn * rn + 0.f * 0.f);
+            mag[0] = m0;
+            smag[0] = m0;
             ph[0] = atan2f(0.f, r0);
-            mag[nc] = sqrtf(rn * rn + 0.f * 0.f);
+            mag[nc] = mn;
+            smag[nc] = mn;
             ph[nc] = atan2f(0.f, rn);
         } else {
             const float2 fpk = buf[k];
@@ -143,16 +162,46 @@ __global__ __launch_bounds__(kFftThreads) void pv_analyze_kernel(const AnalyzeAr
             const float2 fpnk = make_float2(q.x, -q.y);
             const float2 f1k = cadd(fpk, fpnk);
             const float2 f2k = csub(fpk, fpnk);
-            const float2 t = cmul(f2k, tb.st_fwd[k]);
-            const float xr = (f1k.x + t.x) * 0.5f, xi = (f1k.y + t.y) * 0.5f;
-            const float yr = (f1k.x - t.x) * 0.5f, yi = (t.y - f1k.y) * 0.5f;
+            const float2 tq = cmul(f2k, tb.st_fwd[k]);
+            const float xr = (f1k.x + tq.x) * 0.5f, xi = (f1k.y + tq.y) * 0.5f;
+            const float yr = (f1k.x - tq.x) * 0.5f, yi = (tq.y - f1k.y) * 0.5f;
             if (k != nc - k) {
-                mag[k] = sqrtf(xr * xr + xi * xi);
+                const float m = sqrtf(xr * xr + xi * xi);
+                mag[k] = m;
+                smag[k] = m;
                 ph[k] = atan2f(xi, xr);
             }
-            mag[nc - k] = sqrtf(yr * yr + yi * yi);
+            const float m2 = sqrtf(yr * yr + yi * yi);
+            mag[nc - k] = m2;
+            smag[nc - k] = m2;
             ph[nc - k] = atan2f(yi, yr);
         }
+    }
+    if (!a.find_peaks) return;
+    __syncthreads();
+
+    // ordered compaction of the peak bins: ballot per 64-bin group, prefix over groups in bin order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nt >> 6;
+    const int J = (hs + nt - 1) / nt;
+    for (int j = 0; j < J; ++j) {
+        const unsigned long long bm = __ballot(is_peak(smag, threadIdx.x + j * nt, hs));
+        if (lane == 0) wcnt[j * nw + wave] = __popcll(bm);
+    }
+    __syncthreads();
+    uint16_t *__restrict__ pk = a.peaks + plane * a.PKP;
+    int running = 0, qi = 0;
+    for (int j = 0; j < J; ++j) {
+        const int mine = j * nw + wave;
+        for (; qi < mine; ++qi) running += wcnt[qi];
+        const int b = threadIdx.x + j * nt;
+        const bool isp = is_peak(smag, b, hs);
+        const unsigned long long bm = __ballot(isp);
+        if (isp) pk[running + __popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)b;
+    }
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int q = 0; q < J * nw; ++q) total += wcnt[q];
+        a.npk[plane] = total;
     }
 }
 
@@ -166,222 +215,300 @@ template <typename K> static void allow_big_lds(K kernel, bool &done) {
 
 void launch_analyze(const AnalyzeArgs &a, hipStream_t st) {
     const int grid = 8 * ((a.rows + 7) / 8) * a.Tn;
-    const size_t lds = (size_t)a.tb.nc * sizeof(float2);
+    const int J = (a.tb.hs + kFftThreads - 1) / kFftThreads;
+    const size_t lds = (size_t)a.tb.nc * sizeof(float2) + sizeof(float) * (a.tb.hs + 4) + sizeof(int) * (J + 1) * 4;
     hipLaunchKernelGGL(pv_analyze_kernel, dim3(grid), dim3(kFftThreads), lds, st, a);
 }
 
 // --------------------------------------------------------------------------------------------
-// phase propagation: one workgroup per stream, sequential over (slice, channel) in the reference's
-// processing order ch0, ch1, ch0, ... (phasevocoderprocess.cc:281-284); parallel over bins.
-// The peak lists are per STREAM, not per channel: that is the reference's Impl-member quirk
-// (phasevocoderimpl.h:236-238).
+// phase-locked mode, parallel part: for every peak of every step, the matched previous peak and
+// everything about the rotation that does not depend on the recurrence (modifySlicePhaseLocked :640-664).
+// The peak lists are shared by the channels of a stream in processing order ch0, ch1, ch0, ...
+// (the reference's Impl-member quirk, phasevocoderimpl.h:236-238): the "previous
+// peaks" of step (t, c) are those of (t, c-1), or of (t-1, C-1) when c == 0.
 // --------------------------------------------------------------------------------------------
-int phase_threads(int hs) { return hs < 1024 ? hs : 1024; }
+constexpr int kMatchThreads = 128;
 
-size_t phase_lds_bytes(int hs, int C, int pkmax) {
-    // smag[hs] sph[hs] prev_phase[C][hs] prev_out[C][hs] pk[2][pkmax] rot[pkmax] bnd[pkmax] wcnt[64] misc[4]
-    return sizeof(float) * ((size_t)2 * hs + (size_t)2 * C * hs + (size_t)4 * pkmax + 64 + 4);
+__global__ __launch_bounds__(kMatchThreads) void pv_match_kernel(const MatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint16_t *scur = reinterpret_cast<uint16_t *>(smem_raw); // [PKP]
+    uint16_t *sprev = scur + a.PKP;                          // [PKP] peaks of the previous step (other channel)
+    uint16_t *ssame = sprev + a.PKP;                         // [PKP] peaks of the previous slice, same channel
+    const int tl = blockIdx.x, row = blockIdx.y, nt = blockDim.x, tid = threadIdx.x;
+    const int s = row / a.C, c = row - s * a.C;
+    const int64_t t = a.t0 + tl;
+    const int slot = (int)(t % a.TR);
+    const int64_t plane = (int64_t)row * a.TR + slot;
+    const int ncur = a.npk[plane];
+    int64_t pplane = -1; // plane of the previous step
+    if (c > 0) pplane = (int64_t)(row - 1) * a.TR + slot;
+    else if (t > 0) pplane = (int64_t)(s * a.C + a.C - 1) * a.TR + (int)((t - 1) % a.TR);
+    const int nprev = pplane >= 0 ? a.npk[pplane] : 0;
+    const bool first = (t == 0 && c == 0);
+    const int mode = first ? kModeInit : ((ncur == 0 || nprev == 0) ? kModeProp : kModeLock);
+    if (tid == 0) a.modes[plane] = mode;
+    if (mode != kModeLock) return;
+    const int64_t splane = t > 0 ? (int64_t)row * a.TR + (int)((t - 1) % a.TR) : -1;
+    const int nsame = splane >= 0 ? a.npk[splane] : 0;
+    for (int i = tid; i < ncur; i += nt) scur[i] = a.peaks[plane * a.PKP + i];
+    for (int i = tid; i < nprev; i += nt) sprev[i] = a.peaks[pplane * a.PKP + i];
+    for (int i = tid; i < nsame; i += nt) ssame[i] = a.peaks[splane * a.PKP + i];
+    __syncthreads();
+    const float *__restrict__ A2 = a.phase + plane * a.HP;
+    const float *__restrict__ A1 = splane >= 0 ? a.phase + splane * a.HP : nullptr;
+    const float pinc_f = (float)a.phase_inc[tl], hop_f = (float)a.hop;
+    const double Nd = (double)a.N;
+    for (int p = tid; p < ncur; p += nt) {
+        const int p2 = scur[p];
+        // nearest previous peak, ties -> lower index (== the reference's monotone greedy walk :644-652)
+        int lo = 0, hi = nprev;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((int)sprev[mid] < p2) lo = mid + 1;
+            else hi = mid;
+        }
+        int sel;
+        if (lo == 0) sel = 0;
+        else if (lo == nprev) sel = nprev - 1;
+        else sel = ((int)sprev[lo] - p2) < (p2 - (int)sprev[lo - 1]) ? lo : lo - 1;
+        const int p1 = sprev[sel];
+        const float avg_p = (float)((double)(p1 + p2) * 0.5);
+        const float pomega = (float)((a.two_pi_hop * (double)(avg_p - 1)) / Nd);
+        const float a2 = A2[p2];
+        const float a1 = A1 ? A1[p1] : 0.f; // prev_phase of this channel == its previous analysis phase
+        const float d1 = a2 - a1 - pomega;
+        const float pdelta = (float)((double)pomega + princarg((double)d1));
+        // region of p1 in the previous same-channel step = number of its boundaries <= p1
+        int r1 = 0;
+        if (nsame > 1) {
+            int l2 = 0, h2 = nsame - 1;
+            while (l2 < h2) {
+                const int mid = (l2 + h2) >> 1;
+                const int bnd = ((int)ssame[mid] + (int)ssame[mid + 1] + 1) >> 1;
+                if (bnd <= p1) l2 = mid + 1;
+                else h2 = mid;
+            }
+            r1 = l2;
+        }
+        PeakRec r;
+        r.adv = (pdelta * pinc_f) / hop_f;
+        r.a2 = a2;
+        r.a1 = a1;
+        r.p1r1 = (uint32_t)p1 | ((uint32_t)r1 << 16);
+        a.recs[plane * a.PKP + p] = r;
+    }
 }
 
-__global__ __launch_bounds__(1024) void pv_phase_kernel(const PhaseArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int hs = a.hs, C = a.C, nt = blockDim.x, tid = threadIdx.x;
-    const int bpt = hs / nt; // bins per thread (1 or more)
-    float *smag = reinterpret_cast<float *>(smem_raw);
-    float *sph = smag + hs;
-    float *sprev_phase = sph + hs;           // [C][hs]
-    float *sprev_out = sprev_phase + C * hs; // [C][hs]
-    int *pk0 = reinterpret_cast<int *>(sprev_out + C * hs);
-    int *pk1 = pk0 + a.pkmax;
-    float *rot = reinterpret_cast<float *>(pk1 + a.pkmax);
-    int *bnd = reinterpret_cast<int *>(rot + a.pkmax);
-    int *wcnt = bnd + a.pkmax; // [64]
-    int *misc = wcnt + 64;     // [0] = npeak of the current step
+void launch_match(const MatchArgs &a, hipStream_t st) {
+    const size_t lds = sizeof(uint16_t) * 3 * a.PKP;
+    hipLaunchKernelGGL(pv_match_kernel, dim3(a.Tn, a.rows), dim3(kMatchThreads), lds, st, a);
+}
 
-    const int s = blockIdx.x;
-    const int lane = tid & 63, wave = tid >> 6, nwaves = (nt + 63) >> 6;
-
-    // load persistent state
-    for (int i = tid; i < C * hs; i += nt) {
-        sprev_phase[i] = a.st_prev_phase[(int64_t)s * C * hs + i];
-        sprev_out[i] = a.st_prev_out[(int64_t)s * C * hs + i];
+// --------------------------------------------------------------------------------------------
+// phase-locked mode, sequential part: one workgroup per (stream, channel) row walks its slices in
+// order.  In a LOCK step only the peaks carry the recurrence:
+//   target = princarg(prev_out[p1] + adv),  rot = princarg(target - phase[p2])         (:664-665)
+// and prev_out[p1] of a locked previous step is princarg(prev_phase[p1] + rot_prev[region(p1)]) (:688,697),
+// evaluated lazily here.  Every other bin's output phase is applied later, in parallel, by the
+// synthesis kernel.  INIT / PROP steps (first slice, silence: no peaks) take the per-bin path (:606-636).
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ int region_of(const uint16_t *pk, int n, int i) {
+    // number of boundaries round((pk[j] + pk[j+1]) / 2) (half away from zero, :676-682) that are <= i
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int bnd = ((int)pk[mid] + (int)pk[mid + 1] + 1) >> 1;
+        if (bnd <= i) lo = mid + 1;
+        else hi = mid;
     }
-    int nprev = a.st_npeaks[s];
-    int *pk_prev = pk0, *pk_cur = pk1;
-    for (int i = tid; i < nprev; i += nt) pk_prev[i] = a.st_peaks[(int64_t)s * a.pkmax + i];
-    __syncthreads();
+    return lo;
+}
 
+__global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *srot0 = reinterpret_cast<float *>(smem_raw);          // [PKP]
+    float *srot1 = srot0 + a.PKP;                                // [PKP]
+    float *spo = srot1 + a.PKP;                                  // [hs] full prev_out (valid when kind == 1)
+    uint16_t *spk = reinterpret_cast<uint16_t *>(spo + a.hs);    // [PKP] peaks of the previous same-row step
+    const int row = blockIdx.x, nt = blockDim.x, tid = threadIdx.x, hs = a.hs;
+    const int c = row % a.C;
+    int kind = a.st_kind[row];
+    float *rprev = srot0, *rcur = srot1;
+    if (kind == 2)
+        for (int i = tid; i < a.PKP; i += nt) rprev[i] = a.st_rot[(int64_t)row * a.PKP + i];
+    if (kind == 1)
+        for (int i = tid; i < hs; i += nt) spo[i] = a.st_po[(int64_t)row * hs + i];
+    __syncthreads();
     const float hop_f = (float)a.hop;
     const double Nd = (double)a.N;
 
     for (int tl = 0; tl < a.Tn; ++tl) {
-        const float pinc_f = (float)a.phase_inc[tl];
-        for (int c = 0; c < C; ++c) {
-            const int64_t base = (((int64_t)s * C + c) * a.Tc + tl) * a.HP;
-            float *__restrict__ gph = a.phase + base;
-            const float *__restrict__ gmag = a.mag + base;
-            float *pp = sprev_phase + c * hs;
-            float *po = sprev_out + c * hs;
-            const bool first = (a.t0 + tl == 0) && (c == 0);
-
-            if (a.coremode == 2) {
-                // modifySliceIntRatio (:567-570): no state, not even firstentry
-                for (int j = 0; j < bpt; ++j) {
-                    const int i = tid + j * nt;
-                    gph[i] = gph[i] * pinc_f / hop_f;
-                }
-                continue;
+        const int64_t t = a.t0 + tl;
+        const int slot = (int)(t % a.TR);
+        const int64_t plane = (int64_t)row * a.TR + slot;
+        const int mode = a.modes[plane];
+        if (mode == kModeLock) {
+            const int n = a.npk[plane];
+            for (int p = tid; p < n; p += nt) {
+                const PeakRec r = a.recs[plane * a.PKP + p];
+                float po;
+                if (kind == 2) po = (float)princarg((double)(r.a1 + rprev[r.p1r1 >> 16]));
+                else if (kind == 1) po = spo[r.p1r1 & 0xffffu];
+                else po = 0.f;
+                const float tgt = (float)princarg((double)(po + r.adv));
+                const float rt = (float)princarg((double)(tgt - r.a2));
+                rcur[p] = rt;
+                a.rot[plane * a.PKP + p] = rt;
             }
-
-            for (int j = 0; j < bpt; ++j) {
-                const int i = tid + j * nt;
-                sph[i] = gph[i];
-                if (a.coremode == 1) smag[i] = gmag[i];
-            }
-            __syncthreads();
-
-            int npeak = 0;
-            if (a.coremode == 1) {
-                // (i) peak picking, ordered compaction with wave ballots
-                unsigned long long bal[4];
-                for (int j = 0; j < bpt; ++j) {
-                    const int b = tid + j * nt;
-                    bool isp = false;
-                    if (b >= 2 && b + 2 < hs) {
-                        const float mb = smag[b];
-                        isp = mb > smag[b - 1] && mb > smag[b - 2] && mb > smag[b + 1] && mb > smag[b + 2];
-                    }
-                    bal[j & 3] = __ballot(isp);
-                    if (lane == 0) wcnt[j * nwaves + wave] = __popcll(bal[j & 3]);
-                }
-                __syncthreads();
-                int total = 0;
-                for (int q = 0; q < bpt * nwaves; ++q) total += wcnt[q];
-                npeak = total;
-                for (int j = 0; j < bpt; ++j) {
-                    int off = 0;
-                    for (int q = 0; q < j * nwaves + wave; ++q) off += wcnt[q];
-                    const unsigned long long bm = bal[j & 3];
-                    if ((bm >> lane) & 1ull) {
-                        const int idx = off + __popcll(bm & ((1ull << lane) - 1ull));
-                        pk_cur[idx] = tid + j * nt;
-                    }
-                }
+            kind = 2;
+            float *tmp = rprev;
+            rprev = rcur;
+            rcur = tmp;
+        } else {
+            // per-bin path; first materialise prev_out when the previous step of this row was locked
+            const float *__restrict__ A = a.phase + plane * a.HP;
+            const int64_t splane = t > 0 ? (int64_t)row * a.TR + (int)((t - 1) % a.TR) : -1;
+            const float *__restrict__ Ap = splane >= 0 ? a.phase + splane * a.HP : nullptr;
+            int nsame = 0;
+            if (kind == 2) {
+                nsame = a.npk[splane];
+                for (int i = tid; i < nsame; i += nt) spk[i] = a.peaks[splane * a.PKP + i];
                 __syncthreads();
             }
-
-            if (first) {
-                // init branch (:606-616 / :718-728): output phase = input phase, state = input phase
-                for (int j = 0; j < bpt; ++j) {
-                    const int i = tid + j * nt;
-                    const float tp = sph[i];
-                    pp[i] = tp;
-                    po[i] = tp;
-                }
-            } else if (a.coremode != 1 || npeak == 0 || nprev == 0) {
-                // per-bin propagation (:620-636 / :732-748)
-                for (int j = 0; j < bpt; ++j) {
-                    const int i = tid + j * nt;
-                    const float phi = sph[i];
+            const float pinc_f = (float)a.phase_inc[tl];
+            float *__restrict__ outp = a.outphase + plane * a.HP;
+            for (int i = tid; i < hs; i += nt) {
+                const float phi = A[i];
+                float outv;
+                if (mode == kModeInit) {
+                    outv = phi;
+                } else {
+                    float po;
+                    if (kind == 2) po = (float)princarg((double)(Ap[i] + rprev[region_of(spk, nsame, i)]));
+                    else if (kind == 1) po = spo[i];
+                    else po = 0.f;
+                    const float pp = Ap ? Ap[i] : 0.f;
                     const float omega = (float)((a.two_pi_hop * (double)i) / Nd);
-                    const float d1 = phi - pp[i] - omega;
+                    const float d1 = phi - pp - omega;
                     const float delta = (float)((double)omega + princarg((double)d1));
                     const float advance = delta * pinc_f / hop_f;
-                    const float outp = (float)princarg((double)(po[i] + advance));
-                    pp[i] = phi;
-                    po[i] = outp;
-                    gph[i] = outp;
+                    outv = (float)princarg((double)(po + advance));
                 }
-            } else {
-                // (iv) phase locking (:640-699)
-                for (int p = tid; p < npeak; p += nt) {
-                    const int p2 = pk_cur[p];
-                    // nearest previous peak, ties -> lower index (== the reference's monotone greedy walk)
-                    int lo = 0, hi = nprev;
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (pk_prev[mid] < p2) lo = mid + 1;
-                        else hi = mid;
-                    }
-                    int sel;
-                    if (lo == 0) sel = 0;
-                    else if (lo == nprev) sel = nprev - 1;
-                    else sel = (pk_prev[lo] - p2) < (p2 - pk_prev[lo - 1]) ? lo : lo - 1;
-                    const int p1 = pk_prev[sel];
-                    const float avg_p = (float)((double)(p1 + p2) * 0.5);
-                    const float pomega = (float)((a.two_pi_hop * (double)(avg_p - 1)) / Nd);
-                    const float phi2 = sph[p2];
-                    const float d1 = phi2 - pp[p1] - pomega;
-                    const float pdelta = (float)((double)pomega + princarg((double)d1));
-                    const float tgt = (float)princarg((double)(po[p1] + (pdelta * pinc_f) / hop_f));
-                    rot[p] = (float)princarg((double)(tgt - phi2));
-                    if (p + 1 < npeak) bnd[p] = (p2 + pk_cur[p + 1] + 1) >> 1; // round(x.5) away from zero
-                }
-                __syncthreads();
-                for (int j = 0; j < bpt; ++j) {
-                    const int i = tid + j * nt;
-                    // region = number of boundaries <= i
-                    int lo = 0, hi = npeak - 1;
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (bnd[mid] <= i) lo = mid + 1;
-                        else hi = mid;
-                    }
-                    const float phi = sph[i];
-                    const float locked = (float)princarg((double)(phi + rot[lo]));
-                    // pp/po of OTHER bins were read by the peak loop above (before the barrier) -- safe to update
-                    pp[i] = phi;
-                    po[i] = locked;
-                    gph[i] = locked;
-                }
+                spo[i] = outv;
+                outp[i] = outv;
             }
-            if (a.coremode == 1) {
-                int *t = pk_prev;
-                pk_prev = pk_cur;
-                pk_cur = t;
-                nprev = npeak;
-            }
-            __syncthreads();
+            kind = 1;
         }
+        __syncthreads();
     }
-
-    // store persistent state
-    for (int i = tid; i < C * hs; i += nt) {
-        a.st_prev_phase[(int64_t)s * C * hs + i] = sprev_phase[i];
-        a.st_prev_out[(int64_t)s * C * hs + i] = sprev_out[i];
-    }
-    for (int i = tid; i < nprev; i += nt) a.st_peaks[(int64_t)s * a.pkmax + i] = pk_prev[i];
-    if (tid == 0) a.st_npeaks[s] = nprev;
-    (void)misc;
+    if (kind == 2)
+        for (int i = tid; i < a.PKP; i += nt) a.st_rot[(int64_t)row * a.PKP + i] = rprev[i];
+    if (kind == 1)
+        for (int i = tid; i < hs; i += nt) a.st_po[(int64_t)row * hs + i] = spo[i];
+    if (tid == 0) a.st_kind[row] = kind;
+    (void)c;
 }
 
-void launch_phase(const PhaseArgs &a, int nstreams, hipStream_t st) {
-    const int nt = phase_threads(a.hs);
-    const size_t lds = phase_lds_bytes(a.hs, a.C, a.pkmax);
+void launch_seq(const SeqArgs &a, hipStream_t st) {
+    int nt = (a.PKP + 63) & ~63;
+    if (nt > 1024) nt = 1024;
+    if (nt < 64) nt = 64;
+    const size_t lds = sizeof(float) * ((size_t)2 * a.PKP + a.hs) + sizeof(uint16_t) * a.PKP;
     static bool big = false;
-    allow_big_lds(pv_phase_kernel, big);
-    hipLaunchKernelGGL(pv_phase_kernel, dim3(nstreams), dim3(nt), lds, st, a);
+    allow_big_lds(pv_seq_kernel, big);
+    hipLaunchKernelGGL(pv_seq_kernel, dim3(a.rows), dim3(nt), lds, st, a);
 }
 
 // --------------------------------------------------------------------------------------------
-// synthesis
+// coremode 0 (modifySliceSimple :708-753): independent per-bin recurrences; one thread per bin streams
+// over the slices of the launch with its state in registers.
+// --------------------------------------------------------------------------------------------
+constexpr int kPropThreads = 256;
+
+__global__ __launch_bounds__(kPropThreads) void pv_prop_kernel(const PropArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    if (i >= a.hs) return;
+    const int c = row % a.C;
+    float pp = a.st_pp[(int64_t)row * a.hs + i], po = a.st_po[(int64_t)row * a.hs + i];
+    const float omega = (float)((a.two_pi_hop * (double)i) / (double)a.N);
+    const float hop_f = (float)a.hop;
+    for (int tl = 0; tl < a.Tn; ++tl) {
+        const int64_t t = a.t0 + tl;
+        const int64_t plane = (int64_t)row * a.TR + (int)(t % a.TR);
+        const float phi = a.phase[plane * a.HP + i];
+        float outv;
+        if (t == 0 && c == 0) {
+            outv = phi; // firstentry: only the very first step of the stream (function-static in the reference)
+        } else {
+            const float d1 = phi - pp - omega;
+            const float delta = (float)((double)omega + princarg((double)d1));
+            const float advance = delta * (float)a.phase_inc[tl] / hop_f;
+            outv = (float)princarg((double)(po + advance));
+        }
+        pp = phi;
+        po = outv;
+        a.outphase[plane * a.HP + i] = outv;
+    }
+    a.st_pp[(int64_t)row * a.hs + i] = pp;
+    a.st_po[(int64_t)row * a.hs + i] = po;
+}
+
+void launch_prop(const PropArgs &a, hipStream_t st) {
+    hipLaunchKernelGGL(pv_prop_kernel, dim3((a.hs + kPropThreads - 1) / kPropThreads, a.rows), dim3(kPropThreads), 0,
+                       st, a);
+}
+
+// --------------------------------------------------------------------------------------------
+// synthesis (+ per-bin application of the phase modification)
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const DevTables &tb = a.tb;
     const int N = tb.N, hs = tb.hs, nc = tb.nc, nt = blockDim.x;
-    float2 *buf = reinterpret_cast<float2 *>(smem_raw); // [nc]
-    float2 *X = buf + nc;                               // [nc + 1]
+    float2 *buf = reinterpret_cast<float2 *>(smem_raw);        // [nc]
+    float2 *X = buf + nc;                                      // [nc + 1]
+    float *sph = reinterpret_cast<float *>(X + nc + 1);        // [hs + 1] output phase of every bin
+    float *srot = sph + hs + 4;                                // [PKP]
+    uint16_t *spk = reinterpret_cast<uint16_t *>(srot + a.PKP); // [PKP]
     int row, tl;
     if (!block_to_row_slice(a.Tn, a.rows, row, tl)) return;
-    const float *__restrict__ mag = a.mag + ((int64_t)row * a.Tc + tl) * tb.HP;
-    const float *__restrict__ ph = a.phase + ((int64_t)row * a.Tc + tl) * tb.HP;
+    const int64_t t = a.t0 + tl;
+    const int64_t plane = (int64_t)row * a.TR + (int)(t % a.TR);
+    const float *__restrict__ mag = a.mag + plane * tb.HP;
+    const float *__restrict__ A = a.phase + plane * tb.HP;
     const double Nd = (double)N;
 
+    // 1. output phase of every bin
+    if (a.robotic) {
+        for (int k = threadIdx.x; k <= hs; k += nt) sph[k] = 0.f;
+    } else if (a.coremode == 2) {
+        const float pinc_f = (float)a.phase_inc[tl], hop_f = (float)a.hop;
+        for (int k = threadIdx.x; k <= hs; k += nt) sph[k] = k < hs ? A[k] * pinc_f / hop_f : A[k];
+    } else {
+        const int mode = a.coremode == 1 ? a.modes[plane] : kModeProp;
+        if (mode == kModeLock) {
+            const int n = a.npk[plane];
+            for (int i = threadIdx.x; i < n; i += nt) {
+                spk[i] = a.peaks[plane * a.PKP + i];
+                srot[i] = a.rot[plane * a.PKP + i];
+            }
+            __syncthreads();
+            for (int k = threadIdx.x; k <= hs; k += nt) {
+                const float phi = A[k];
+                sph[k] = k < hs ? (float)princarg((double)(phi + srot[region_of(spk, n, k)])) : phi;
+            }
+        } else {
+            const float *__restrict__ op = a.outphase + plane * tb.HP;
+            for (int k = threadIdx.x; k <= hs; k += nt) sph[k] = k < hs ? op[k] : A[k];
+        }
+    }
+    __syncthreads();
+
+    // 2. spectrum: freqCompSlice gather (:869-916, both branches are pure gathers from the pre-call arrays),
+    //    gains, polar -> cartesian (FFT.cc:2711-2718)
     for (int k = threadIdx.x; k <= hs; k += nt) {
         float mg, p;
         if (a.do_freq_comp) {
-            // freqCompSlice (:869-916): both branches are pure gathers from the pre-call arrays
             if (a.freq_comp > 1.0f) {
                 const int src = __float2int_rn((float)k * a.freq_comp);
                 if (src > hs) {
@@ -389,28 +516,27 @@ __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a
                     p = 0.f;
                 } else {
                     mg = mag[src];
-                    p = ph[src] + (float)((a.two_pi_hop * (double)(k - src)) / Nd);
+                    p = sph[src] + (float)((a.two_pi_hop * (double)(k - src)) / Nd);
                 }
             } else if (k < hs) {
                 const int src = __float2int_rn((float)k * a.freq_comp);
                 mg = mag[src];
-                p = ph[src] + (float)((a.two_pi_hop * (double)(k - src)) / Nd);
+                p = sph[src] + (float)((a.two_pi_hop * (double)(k - src)) / Nd);
             } else {
                 mg = mag[k];
-                p = ph[k];
+                p = sph[k];
             }
             mg *= a.fixed_gain;
         } else {
             mg = mag[k];
-            p = ph[k];
+            p = sph[k];
         }
-        if (a.robotic) p = 0.f;
         mg *= a.inv_n;
         X[k] = make_float2(mg * cosf(p), mg * sinf(p));
     }
     __syncthreads();
 
-    // kiss_fftri pre-pass (kiss_fftr.c:134-157), scattered straight into butterfly order
+    // 3. kiss_fftri pre-pass (kiss_fftr.c:134-157), scattered straight into butterfly order
     for (int k = threadIdx.x; k <= nc / 2; k += nt) {
         if (k == 0) {
             buf[tb.iperm[0]] = make_float2(X[0].x + X[nc].x, X[0].x - X[nc].x);
@@ -419,8 +545,8 @@ __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a
             const float2 q = X[nc - k];
             const float2 fnkc = make_float2(q.x, -q.y);
             const float2 fek = cadd(fk, fnkc);
-            const float2 t = csub(fk, fnkc);
-            const float2 fok = cmul(t, tb.st_inv[k]);
+            const float2 tq = csub(fk, fnkc);
+            const float2 fok = cmul(tq, tb.st_inv[k]);
             const float2 u = cadd(fek, fok);
             float2 v = csub(fek, fok);
             v.y = v.y * -1.f;
@@ -431,17 +557,18 @@ __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a
     __syncthreads();
     fft_stages<true>(buf, tb, tb.tw_inv);
 
-    // ifftshift + synthesis window (phasevocoderimpl.h:183-198)
+    // 4. ifftshift + synthesis window (phasevocoderimpl.h:183-198)
     const float *fb = reinterpret_cast<const float *>(buf);
-    const int slot = (int)((a.t0 + tl) & (int64_t)(a.FR - 1));
-    float *__restrict__ out = a.frames + ((int64_t)row * a.FR + slot) * N;
+    const int fslot = (int)(t & (int64_t)(a.FR - 1));
+    float *__restrict__ out = a.frames + ((int64_t)row * a.FR + fslot) * N;
     const float *__restrict__ w = tb.window;
     for (int i = threadIdx.x; i < N; i += nt) out[i] = fb[(i + hs) & (N - 1)] * w[i];
 }
 
 void launch_synth(const SynthArgs &a, hipStream_t st) {
     const int grid = 8 * ((a.rows + 7) / 8) * a.Tn;
-    const size_t lds = (size_t)(2 * a.tb.nc + 1) * sizeof(float2);
+    const size_t lds = (size_t)(2 * a.tb.nc + 1) * sizeof(float2) + sizeof(float) * (a.tb.hs + 4 + a.PKP) +
+                       sizeof(uint16_t) * a.PKP;
     static bool big = false;
     allow_big_lds(pv_synth_kernel, big);
     hipLaunchKernelGGL(pv_synth_kernel, dim3(grid), dim3(kFftThreads), lds, st, a);

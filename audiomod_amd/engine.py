@@ -22,7 +22,8 @@ MODES = {"constant": -1, "normal_pitchshift": 0, "gender_change": 1, "formant_pi
 CONSTANT, NORMAL_SHIFT, GENDER_CHANGE, FORMANT_PRESERVE = -1, 0, 1, 2
 VOCODER_ROSENBERG, VOCODER_CHORD, NORMAL_STRETCH, ROBOTIC, WHISPER = 3, 4, 5, 6, 7
 NORMAL_PV, PHASE_LOCKED, INT_RATIO = 0, 1, 2
-KERNELS = ("pv_analyze_kernel", "pv_phase_kernel", "pv_synth_kernel", "pv_ola_kernel")
+KERNELS = ("pv_analyze_kernel", "pv_match_kernel", "pv_seq_kernel", "pv_prop_kernel", "pv_synth_kernel",
+           "pv_ola_kernel")
 
 
 class PvError(RuntimeError):
@@ -299,7 +300,7 @@ class Batch:
 
     def kernel_times(self):
         """{kernel: (total_ms, launches)} since enable_timing; synchronise the stream first."""
-        ms = (C.c_double * 4)()
-        n = (C.c_int64 * 4)()
+        ms = (C.c_double * len(KERNELS))()
+        n = (C.c_int64 * len(KERNELS))()
         _check(self.L.pv_batch_kernel_times(self.h, ms, n), "pv_batch_kernel_times")
-        return {KERNELS[k]: (ms[k], n[k]) for k in range(4)}
+        return {KERNELS[k]: (ms[k], n[k]) for k in range(len(KERNELS))}

@@ -131,22 +131,34 @@ def main():
         xrt_gpu = args.streams * args.seconds * args.steps / dt
         slices_per_launch_total = batch.slices * 2 * args.streams  # per step, all chunks
         N, H, s, h = info["fftsize"], info["fftsize"] // 2 + 1, info["hop_out_nominal"], info["hop_in"]
-        kbytes = {  # algorithmic bytes per slice of each kernel: sums to 4*(3N+7H+2s+h)
-            "pv_analyze_kernel": 4 * (N + 2 * H),
-            "pv_phase_kernel": 4 * (3 * H),
-            "pv_synth_kernel": 4 * (2 * H + N),
-            "pv_ola_kernel": 4 * (N + 2 * s + h),
+        # Algorithmic bytes per slice of each pipeline stage; they sum to SURVEY 8(d)'s
+        # B_slice = 4*(3N+7H+2s+h).  The phase stage runs as two kernels (match + seq) in phase-locked
+        # mode and as one (prop) in coremode 0; a stage's time is the sum over its kernels.
+        stages = {
+            "analysis": (4 * (N + 2 * H), ["pv_analyze_kernel"]),
+            "phase": (4 * (3 * H), ["pv_match_kernel", "pv_seq_kernel", "pv_prop_kernel"]),
+            "synthesis": (4 * (2 * H + N), ["pv_synth_kernel"]),
+            "ola_resample": (4 * (N + 2 * s + h), ["pv_ola_kernel"]),
         }
-        assert sum(kbytes.values()) == info["bytes_per_slice"]
-        per_kernel = {}
+        assert sum(b for b, _ in stages.values()) == info["bytes_per_slice"]
+        per_kernel, per_stage = {}, {}
         for k, (ms, n) in ktimes.items():
             if n:
-                slices_per_launch = slices_per_launch_total * args.steps / n
-                avg_ms = ms / n
-                per_kernel[k] = {"avg_ms": round(avg_ms, 4), "launches": int(n), "total_ms": round(ms, 2),
-                                 "GBps": round(kbytes[k] * slices_per_launch / (avg_ms * 1e-3) / 1e9, 1)}
-        dom = max(per_kernel, key=lambda k: per_kernel[k]["total_ms"])
-        achieved = per_kernel[dom]["GBps"]
+                per_kernel[k] = {"avg_ms": round(ms / n, 4), "launches": int(n), "total_ms": round(ms, 2)}
+        for name, (nbytes, ks) in stages.items():
+            live = [k for k in ks if k in per_kernel]
+            if not live:
+                continue
+            launches = per_kernel[live[0]]["launches"]
+            total_ms = sum(per_kernel[k]["total_ms"] for k in live)
+            slices_per_launch = slices_per_launch_total * args.steps / launches
+            avg_ms = total_ms / launches
+            per_stage[name] = {"kernels": live, "avg_ms": round(avg_ms, 4), "total_ms": round(total_ms, 2),
+                               "bytes_per_slice": nbytes, "slices_per_launch": round(slices_per_launch, 1),
+                               "GBps": round(nbytes * slices_per_launch / (avg_ms * 1e-3) / 1e9, 1)}
+        dom_stage = max(per_stage, key=lambda k: per_stage[k]["total_ms"])
+        dom = max(per_stage[dom_stage]["kernels"], key=lambda k: per_kernel[k]["total_ms"])
+        achieved = per_stage[dom_stage]["GBps"]
         pipeline_gbps = info["bytes_per_slice"] * slices_per_launch_total * args.steps / dt / 1e9
         line = {
             "metric": "Msamples/s (48 kHz stereo) phase-vocoder pitch-shift; x real-time per GPU",
@@ -161,7 +173,8 @@ def main():
                        "parallelism": f"stream-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "pipeline_GBps": round(pipeline_gbps, 1), "per_kernel": per_kernel},
+                         "stage": dom_stage, "pipeline_GBps": round(pipeline_gbps, 1), "per_stage": per_stage,
+                         "per_kernel": per_kernel},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

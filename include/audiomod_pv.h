@@ -130,11 +130,13 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
 /* Optional per-kernel timing of the NEXT pv_batch_run calls (HIP events on the run's stream).
  * After synchronising the stream, pv_batch_kernel_times returns, for each of PV_NUM_KERNELS
  * kernels, the summed device time in ms and the launch count since timing was enabled. */
-#define PV_NUM_KERNELS 4
-#define PV_K_ANALYZE 0
-#define PV_K_PHASE 1
-#define PV_K_SYNTH 2
-#define PV_K_OLA_RESAMPLE 3
+#define PV_NUM_KERNELS 6
+#define PV_K_ANALYZE 0      /* window + forward real FFT + polar (+ peak picking) */
+#define PV_K_MATCH 1        /* phase-locked: peak matching, parallel part */
+#define PV_K_SEQ 2          /* phase-locked: per-peak rotation chain, sequential over slices */
+#define PV_K_PROP 3         /* coremode 0: per-bin phase recurrence */
+#define PV_K_SYNTH 4        /* phase application + freqComp + inverse real FFT + window */
+#define PV_K_OLA_RESAMPLE 5 /* overlap-add + normalise + resample */
 int pv_batch_enable_timing(pv_batch *b, int on);
 int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launches[PV_NUM_KERNELS]);
 const char *pv_kernel_name(int k);
