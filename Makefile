@@ -26,3 +26,9 @@ ref:
 clean:
 	rm -rf audiomod_amd/lib
 .PHONY: all oracle ref clean
+
+# stand-alone program over the drop-in C++ class (tests/test_shim.py runs it on the GPU box)
+SHIM := audiomod_amd/lib/shim_demo
+$(SHIM): tools/shim_demo.cc $(LIB) include/dafx/phasevocoder.h include/dafx/modbase.h
+	$(HIPCC) -O2 -std=c++17 -Iinclude -Iinclude/dafx tools/shim_demo.cc -Laudiomod_amd/lib -laudiomod_pv -Wl,-rpath,'$$ORIGIN' -o $@
+all: $(SHIM)

@@ -119,10 +119,8 @@ def main():
     dt = time.perf_counter() - t0
     ktimes = batch.kernel_times()
     batch.enable_timing(False)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from audiomod_amd.sharding import max_over_ranks
+    dt = max_over_ranks(dt, dist, device)
 
     if rank == 0:
         total_streams = args.streams * world
