@@ -24,6 +24,7 @@
 // (device libm, a few ulp).  princarg stays in double with a true IEEE divide, as the reference
 // (common/system/sys.h:84,91).
 #include "pv_kernels.h"
+#include "pv_wavefft.h"
 
 #include <hip/hip_runtime.h>
 
@@ -205,6 +206,143 @@ __global__ __launch_bounds__(kFftThreads) void pv_analyze_kernel(const AnalyzeAr
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// analysis, wave-per-frame variant (N = 2048 / 4096): one 64-lane wave owns a slice, the four waves of a
+// workgroup take four consecutive slices of the same row.  No workgroup barrier anywhere.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync() {
+    // LDS operations of one wave execute in issue order; this only stops the compiler from moving LDS
+    // accesses across the hand-off between two passes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ bool block_to_row_slice4(int Tn, int rows, int &row, int &tl) {
+    const int groups = (Tn + 3) >> 2;
+    const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+    row = xcd + 8 * (q / groups);
+    tl = 4 * (q % groups) + (threadIdx.x >> 6);
+    return row < rows && tl < Tn;
+}
+
+template <int NC> __global__ __launch_bounds__(256) void pv_analyze_wave_kernel(const AnalyzeArgs a) {
+    using W = WF<NC>;
+    constexpr int N = 2 * NC, hs = NC, R = W::R;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    cf *lds = reinterpret_cast<cf *>(smem_raw) + wave * W::LDS_CF;
+    int row, tl;
+    if (!block_to_row_slice4(a.Tn, a.rows, row, tl)) return; // wave-uniform
+    const DevTables &tb = a.tb;
+    const int64_t t = a.t0 + tl;
+    const int slot = (int)(t % a.TR);
+    const int64_t a0 = t * (int64_t)a.hop;
+    const float *__restrict__ in = a.ia.in + (int64_t)row * a.ia.stride_c;
+    const float *__restrict__ w = tb.window;
+    const cf *__restrict__ tw = reinterpret_cast<const cf *>(tb.tw_fwd);
+    const cf *__restrict__ stw = reinterpret_cast<const cf *>(tb.st_fwd);
+
+    // windowed, fft-shifted frame straight into the pass-0 register layout: for a fixed register the 64
+    // lanes read one contiguous 512-byte span of the input (permuted among the lanes)
+    cf v[R];
+    {
+        const int lp = wf_lane_part<W>(0, lane);
+        const int lsrc = wf_src_of<W>(lp);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int src = lsrc | wf_src_of_const<W>(wf_reg_part<W>(0, r));
+            const int k0 = (2 * src + hs) & (N - 1);
+            const int64_t g0 = a0 + k0;
+            const float x0 = g0 < a.ia.len ? in[(uint64_t)g0 & a.ia.mask] : 0.f;
+            const float x1 = g0 + 1 < a.ia.len ? in[(uint64_t)(g0 + 1) & a.ia.mask] : 0.f;
+            v[r] = cf{x0 * w[k0], x1 * w[k0 + 1]};
+        }
+    }
+    wf_fft_pass<W, 0, false>(v, lane, lds, tw);
+    wave_sync();
+    wf_fft_pass<W, 1, false>(v, lane, lds, tw);
+    wave_sync();
+    wf_fft_pass<W, 2, false>(v, lane, lds, tw);
+    wave_sync();
+
+    // real-FFT split (kiss_fftr.c:91-120) + polar (FFT.cc:2623-2630); lane handles k = lane + 64 j
+    const int64_t plane = ((int64_t)row * a.TR + slot);
+    float *__restrict__ mag = a.mag + plane * tb.HP;
+    float *__restrict__ ph = a.phase + plane * tb.HP;
+    constexpr int J = NC / 128;
+    float mlo[J], mhi[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = lane + 64 * j;
+        if (j == 0 && lane == 0) {
+            const cf tdc = lds[W::pad(0)];
+            const float r0 = tdc.x + tdc.y, rn = tdc.x - tdc.y;
+            mlo[0] = sqrtf(r0 * r0 + 0.f * 0.f);
+            mhi[0] = sqrtf(rn * rn + 0.f * 0.f);
+            mag[0] = mlo[0];
+            ph[0] = atan2f(0.f, r0);
+            mag[NC] = mhi[0];
+            ph[NC] = atan2f(0.f, rn);
+        } else {
+            const cf fpk = lds[W::pad(k)];
+            const cf q = lds[W::pad(NC - k)];
+            const cf fpnk = cf{q.x, -q.y};
+            const cf f1k = wf_add(fpk, fpnk);
+            const cf f2k = wf_sub(fpk, fpnk);
+            const cf tq = wf_cmul(f2k, stw[k]);
+            const float xr = (f1k.x + tq.x) * 0.5f, xi = (f1k.y + tq.y) * 0.5f;
+            const float yr = (f1k.x - tq.x) * 0.5f, yi = (tq.y - f1k.y) * 0.5f;
+            mlo[j] = sqrtf(xr * xr + xi * xi);
+            mhi[j] = sqrtf(yr * yr + yi * yi);
+            mag[k] = mlo[j];
+            ph[k] = atan2f(xi, xr);
+            mag[NC - k] = mhi[j];
+            ph[NC - k] = atan2f(yi, yr);
+        }
+    }
+    float mmid = 0.f;
+    if (lane == 0) { // k == NC/2 pairs with itself: the second assignment of the reference loop wins
+        const cf fpk = lds[W::pad(NC / 2)];
+        const cf fpnk = cf{fpk.x, -fpk.y};
+        const cf f1k = wf_add(fpk, fpnk);
+        const cf f2k = wf_sub(fpk, fpnk);
+        const cf tq = wf_cmul(f2k, stw[NC / 2]);
+        const float yr = (f1k.x - tq.x) * 0.5f, yi = (tq.y - f1k.y) * 0.5f;
+        mmid = sqrtf(yr * yr + yi * yi);
+        mag[NC / 2] = mmid;
+        ph[NC / 2] = atan2f(yi, yr);
+    }
+    if (!a.find_peaks) return;
+    wave_sync();
+    // magnitudes into the (now free) wave-private LDS region, then ordered peak compaction by ballots
+    float *smag = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = lane + 64 * j;
+        if (j == 0 && lane == 0) {
+            smag[0] = mlo[0];
+            smag[NC] = mhi[0];
+        } else {
+            smag[k] = mlo[j];
+            smag[NC - k] = mhi[j];
+        }
+    }
+    if (lane == 0) smag[NC / 2] = mmid;
+    wave_sync();
+    uint16_t *__restrict__ pk = a.peaks + plane * a.PKP;
+    int running = 0;
+#pragma unroll 4
+    for (int g = 0; g < hs / 64; ++g) {
+        const int b = lane + 64 * g;
+        const bool isp = is_peak(smag, b, hs);
+        const unsigned long long bm = __ballot(isp);
+        if (isp) pk[running + __popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)b;
+        running += __popcll(bm);
+    }
+    if (lane == 0) a.npk[plane] = running;
+}
+
 // kernels may need more than the default 64 KiB of dynamic LDS at the largest FFT sizes
 template <typename K> static void allow_big_lds(K kernel, bool &done) {
     if (done) return;
@@ -214,6 +352,19 @@ template <typename K> static void allow_big_lds(K kernel, bool &done) {
 }
 
 void launch_analyze(const AnalyzeArgs &a, hipStream_t st) {
+    if (a.tb.nc == 1024 || a.tb.nc == 2048) {
+        const int grid4 = 8 * ((a.rows + 7) / 8) * ((a.Tn + 3) / 4);
+        if (a.tb.nc == 1024) {
+            hipLaunchKernelGGL(pv_analyze_wave_kernel<1024>, dim3(grid4), dim3(256), 4 * WF<1024>::LDS_CF * sizeof(cf),
+                               st, a);
+        } else {
+            static bool big = false;
+            allow_big_lds(pv_analyze_wave_kernel<2048>, big);
+            hipLaunchKernelGGL(pv_analyze_wave_kernel<2048>, dim3(grid4), dim3(256), 4 * WF<2048>::LDS_CF * sizeof(cf),
+                               st, a);
+        }
+        return;
+    }
     const int grid = 8 * ((a.rows + 7) / 8) * a.Tn;
     const int J = (a.tb.hs + kFftThreads - 1) / kFftThreads;
     const size_t lds = (size_t)a.tb.nc * sizeof(float2) + sizeof(float) * (a.tb.hs + 4) + sizeof(int) * (J + 1) * 4;
@@ -565,7 +716,197 @@ __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a
     for (int i = threadIdx.x; i < N; i += nt) out[i] = fb[(i + hs) & (N - 1)] * w[i];
 }
 
+// --------------------------------------------------------------------------------------------
+// synthesis, wave-per-frame variant.  The wave-private LDS region is reused four times:
+// [output phases + rot/peak lists] -> [spectrum X] -> [butterfly-ordered input] -> [time-domain frame].
+// --------------------------------------------------------------------------------------------
+template <int NC> __global__ __launch_bounds__(256) void pv_synth_wave_kernel(const SynthArgs a) {
+    using W = WF<NC>;
+    constexpr int N = 2 * NC, hs = NC, R = W::R;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    cf *lds = reinterpret_cast<cf *>(smem_raw) + wave * W::LDS_CF;
+    int row, tl;
+    if (!block_to_row_slice4(a.Tn, a.rows, row, tl)) return; // wave-uniform
+    const DevTables &tb = a.tb;
+    const int64_t t = a.t0 + tl;
+    const int64_t plane = (int64_t)row * a.TR + (int)(t % a.TR);
+    const float *__restrict__ mag = a.mag + plane * tb.HP;
+    const float *__restrict__ A = a.phase + plane * tb.HP;
+    const cf *__restrict__ tw = reinterpret_cast<const cf *>(tb.tw_inv);
+    const cf *__restrict__ stw = reinterpret_cast<const cf *>(tb.st_inv);
+    const double Nd = (double)N;
+    float *sph = reinterpret_cast<float *>(lds);                    // [hs + 1]
+    float *srot = sph + hs + 4;                                     // [PKP]
+    uint16_t *spk = reinterpret_cast<uint16_t *>(srot + a.PKP);     // [PKP]
+    constexpr int JB = NC / 64; // bins per lane (plus the Nyquist bin on lane 0)
+
+    // 1. output phase of every bin -> sph
+    if (a.robotic) {
+#pragma unroll
+        for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = 0.f;
+        if (lane == 0) sph[hs] = 0.f;
+    } else if (a.coremode == 2) {
+        const float pinc_f = (float)a.phase_inc[tl], hop_f = (float)a.hop;
+#pragma unroll
+        for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = A[lane + 64 * j] * pinc_f / hop_f;
+        if (lane == 0) sph[hs] = A[hs];
+    } else {
+        const int mode = a.coremode == 1 ? a.modes[plane] : kModeProp;
+        if (mode == kModeLock) {
+            const int n = a.npk[plane];
+            for (int i = lane; i < n; i += 64) {
+                spk[i] = a.peaks[plane * a.PKP + i];
+                srot[i] = a.rot[plane * a.PKP + i];
+            }
+            wave_sync();
+#pragma unroll 4
+            for (int j = 0; j < JB; ++j) {
+                const int k = lane + 64 * j;
+                sph[k] = (float)princarg((double)(A[k] + srot[region_of(spk, n, k)]));
+            }
+        } else {
+            const float *__restrict__ op = a.outphase + plane * tb.HP;
+#pragma unroll
+            for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = op[lane + 64 * j];
+        }
+        if (lane == 0) sph[hs] = A[hs];
+    }
+    wave_sync();
+
+    // 2. spectrum in registers: freqCompSlice gather (:869-916), gains, polar -> cartesian (FFT.cc:2711-2718)
+    cf xs[JB];
+    cf xnyq = cf{0.f, 0.f};
+    auto spectrum_bin = [&](int k) -> cf {
+        float mg, p;
+        if (a.do_freq_comp) {
+            if (a.freq_comp > 1.0f) {
+                const int src = __float2int_rn((float)k * a.freq_comp);
+                if (src > hs) {
+                    mg = 0.f;
+                    p = 0.f;
+                } else {
+                    mg = mag[src];
+                    p = sph[src] + (float)((a.two_pi_hop * (double)(k - src)) / Nd);
+                }
+            } else if (k < hs) {
+                const int src = __float2int_rn((float)k * a.freq_comp);
+                mg = mag[src];
+                p = sph[src] + (float)((a.two_pi_hop * (double)(k - src)) / Nd);
+            } else {
+                mg = mag[k];
+                p = sph[k];
+            }
+            mg *= a.fixed_gain;
+        } else {
+            mg = mag[k];
+            p = sph[k];
+        }
+        mg *= a.inv_n;
+        float sn, cs;
+        sincosf(p, &sn, &cs);
+        return cf{mg * cs, mg * sn};
+    };
+#pragma unroll
+    for (int j = 0; j < JB; ++j) xs[j] = spectrum_bin(lane + 64 * j);
+    if (lane == 0) xnyq = spectrum_bin(hs);
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < JB; ++j) lds[lane + 64 * j] = xs[j];
+    if (lane == 0) lds[hs] = xnyq;
+    wave_sync();
+
+    // 3. kiss_fftri pre-pass (kiss_fftr.c:134-157): pairs (k, NC-k) into registers, then scattered into
+    //    butterfly order.  k = lane + 64 j; NC - k = 64 * (JB - j - (lane != 0)) + ((64 - lane) & 63).
+    constexpr int J = NC / 128;
+    cf pa[J], pb[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = lane + 64 * j;
+        pa[j] = lds[k];
+        pb[j] = lds[NC - k];
+    }
+    const cf pmid = lds[NC / 2];
+    wave_sync();
+    const int e_lane = wf_e_of_src<W>(lane);             // low six source bits
+    const int e_lane2 = wf_e_of_src<W>((64 - lane) & 63);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        if (j == 0 && lane == 0) {
+            lds[W::pad(wf_e_of_src<W>(0))] = cf{pa[0].x + pb[0].x, pa[0].x - pb[0].x};
+        } else {
+            const cf fk = pa[j];
+            const cf fnkc = cf{pb[j].x, -pb[j].y};
+            const cf fek = wf_add(fk, fnkc);
+            const cf tq = wf_sub(fk, fnkc);
+            const cf fok = wf_cmul(tq, stw[lane + 64 * j]);
+            const cf u = wf_add(fek, fok);
+            cf vv = wf_sub(fek, fok);
+            vv.y = vv.y * -1.f;
+            const int e1 = e_lane | wf_e_of_src<W>(64 * j);
+            const int hi2 = lane != 0 ? wf_e_of_src<W>(64 * (JB - j - 1)) : wf_e_of_src<W>((64 * (JB - j)) & (NC - 1));
+            const int e2 = e_lane2 | hi2;
+            lds[W::pad(e1)] = u;
+            lds[W::pad(e2)] = vv;
+        }
+    }
+    if (lane == 0) { // k == NC/2: only the second assignment survives
+        const cf fk = pmid;
+        const cf fnkc = cf{pmid.x, -pmid.y};
+        const cf fek = wf_add(fk, fnkc);
+        const cf tq = wf_sub(fk, fnkc);
+        const cf fok = wf_cmul(tq, stw[NC / 2]);
+        cf vv = wf_sub(fek, fok);
+        vv.y = vv.y * -1.f;
+        lds[W::pad(wf_e_of_src<W>(NC / 2))] = vv;
+    }
+    wave_sync();
+
+    // 4. inverse complex FFT
+    cf v[R];
+    {
+        const int lp = wf_lane_part<W>(0, lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = lds[W::pad(lp | wf_reg_part<W>(0, r))];
+    }
+    wave_sync();
+    wf_fft_pass<W, 0, true>(v, lane, lds, tw);
+    wave_sync();
+    wf_fft_pass<W, 1, true>(v, lane, lds, tw);
+    wave_sync();
+    wf_fft_pass<W, 2, true>(v, lane, lds, tw);
+    wave_sync();
+
+    // 5. ifftshift + synthesis window (phasevocoderimpl.h:183-198): two consecutive samples per lane
+    const int fslot = (int)(t & (int64_t)(a.FR - 1));
+    float *__restrict__ out = a.frames + ((int64_t)row * a.FR + fslot) * N;
+    const float *__restrict__ w = tb.window;
+#pragma unroll 4
+    for (int j = 0; j < NC / 64; ++j) {
+        const int i = 2 * (lane + 64 * j);        // output sample index (even)
+        const int e = ((i + hs) & (N - 1)) >> 1;  // complex element holding samples i+hs, i+hs+1
+        const cf z = lds[W::pad(e)];
+        const float2 ww = *reinterpret_cast<const float2 *>(w + i);
+        *reinterpret_cast<float2 *>(out + i) = make_float2(z.x * ww.x, z.y * ww.y);
+    }
+}
+
 void launch_synth(const SynthArgs &a, hipStream_t st) {
+    if (a.tb.nc == 1024 || a.tb.nc == 2048) {
+        const int grid4 = 8 * ((a.rows + 7) / 8) * ((a.Tn + 3) / 4);
+        if (a.tb.nc == 1024) {
+            static bool big1 = false;
+            allow_big_lds(pv_synth_wave_kernel<1024>, big1);
+            hipLaunchKernelGGL(pv_synth_wave_kernel<1024>, dim3(grid4), dim3(256), 4 * WF<1024>::LDS_CF * sizeof(cf),
+                               st, a);
+        } else {
+            static bool big2 = false;
+            allow_big_lds(pv_synth_wave_kernel<2048>, big2);
+            hipLaunchKernelGGL(pv_synth_wave_kernel<2048>, dim3(grid4), dim3(256), 4 * WF<2048>::LDS_CF * sizeof(cf),
+                               st, a);
+        }
+        return;
+    }
     const int grid = 8 * ((a.rows + 7) / 8) * a.Tn;
     const size_t lds = (size_t)(2 * a.tb.nc + 1) * sizeof(float2) + sizeof(float) * (a.tb.hs + 4 + a.PKP) +
                        sizeof(uint16_t) * a.PKP;

@@ -1,0 +1,182 @@
+// pv_wavefft.h -- one-wavefront-per-frame complex FFT core (NC = 1024 or 2048 points) for gfx950.
+//
+// A 64-lane wave owns a whole frame: every lane keeps R = NC/64 complex elements in registers, runs
+// two (or three) kissfft butterfly stages on them, and the wave re-distributes the elements through a
+// wave-private LDS region between the three passes.  No workgroup barrier, three LDS round trips
+// instead of five-plus, and 16/32 independent butterflies per lane for latency hiding.
+//
+// Arithmetic is kissfft's, operation for operation (kiss_fft.c:36-103): same stage order (innermost
+// recursion level first: m = 1, 4, 16, ... for 1024 = 4^5; radix-2 then m = 2, 8, 32, ... for
+// 2048 = 4^5 * 2), same twiddle table entries tw[k*fstride*q], same operand order -- so results are
+// bit-identical to the reference (and to the generic LDS kernel in pv_kernels.hip).
+//
+// The element index e (position in the butterfly-ordered array) is treated as a bit string; each pass
+// assigns some bits to the register index r and the other six to the lane.  Everything about the
+// register side is resolved at compile time after full unrolling.
+//
+// The functions are __host__ __device__ so tests/host_wavefft.cc can run the exact same index math on
+// the CPU, lane by lane, against the oracle.
+#pragma once
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PV_HD __host__ __device__ __forceinline__
+#else
+#define PV_HD inline
+#endif
+
+namespace pv {
+
+struct alignas(8) cf {
+    float x, y;
+};
+
+PV_HD cf wf_cmul(cf a, cf b) {
+    cf m;
+    m.x = a.x * b.x - a.y * b.y;
+    m.y = a.x * b.y + a.y * b.x;
+    return m;
+}
+PV_HD cf wf_add(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
+PV_HD cf wf_sub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+
+template <int NC> struct WF;
+
+template <> struct WF<1024> {
+    static constexpr int N_C = 1024, LOG = 10, R = 16, RB = 4, NSTAGE = 5;
+    static constexpr int st_radix[6] = {4, 4, 4, 4, 4, 0};
+    static constexpr int st_bit[6] = {0, 2, 4, 6, 8, 0};
+    static constexpr int st_pass[6] = {0, 0, 1, 1, 2, 0};
+    static constexpr int regpos[3][5] = {{0, 1, 2, 3, 0}, {4, 5, 6, 7, 0}, {6, 7, 8, 9, 0}};
+    static constexpr int lanepos[3][6] = {{4, 5, 6, 7, 8, 9}, {0, 1, 2, 3, 8, 9}, {0, 1, 2, 3, 4, 5}};
+    // kissfft's leaf copy: e = d0 + 4 d1 + 16 d2 + 64 d3 + 256 d4  <-  src = d4 + 4 d3 + 16 d2 + 64 d1 + 256 d0
+    static constexpr int srcbit[11] = {8, 9, 6, 7, 4, 5, 2, 3, 0, 1, 0};
+    static PV_HD int pad(int e) { return e + (e >> 4); }
+    static constexpr int LDS_CF = 1024 + 64 + 8; // cf slots of the wave-private region
+};
+
+template <> struct WF<2048> {
+    static constexpr int N_C = 2048, LOG = 11, R = 32, RB = 5, NSTAGE = 6;
+    static constexpr int st_radix[6] = {2, 4, 4, 4, 4, 4};
+    static constexpr int st_bit[6] = {0, 1, 3, 5, 7, 9};
+    static constexpr int st_pass[6] = {0, 0, 0, 1, 1, 2};
+    static constexpr int regpos[3][5] = {{0, 1, 2, 3, 4}, {0, 5, 6, 7, 8}, {0, 7, 8, 9, 10}};
+    static constexpr int lanepos[3][6] = {{5, 6, 7, 8, 9, 10}, {1, 2, 3, 4, 9, 10}, {1, 2, 3, 4, 5, 6}};
+    // e = b + 2 (d1 + 4 d2 + 16 d3 + 64 d4 + 256 d5)  <-  src = d5 + 4 d4 + 16 d3 + 64 d2 + 256 d1 + 1024 b
+    static constexpr int srcbit[11] = {10, 8, 9, 6, 7, 4, 5, 2, 3, 0, 1};
+    static PV_HD int pad(int e) { return e + (e >> 4) + (e >> 8); }
+    static constexpr int LDS_CF = 2048 + 128 + 8 + 8;
+};
+
+// ---- compile-time helpers ------------------------------------------------------------------
+template <class W> constexpr int wf_reg_part(int pass, int r) {
+    int e = 0;
+    for (int i = 0; i < W::RB; ++i) e |= ((r >> i) & 1) << W::regpos[pass][i];
+    return e;
+}
+template <class W> constexpr int wf_find_regbit(int pass, int ebit) {
+    for (int i = 0; i < W::RB; ++i)
+        if (W::regpos[pass][i] == ebit) return i;
+    return -1;
+}
+// source (pre-permutation) index of butterfly-order index e
+template <class W> constexpr int wf_src_of_const(int e) {
+    int s = 0;
+    for (int i = 0; i < W::LOG; ++i) s |= ((e >> i) & 1) << W::srcbit[i];
+    return s;
+}
+template <class W> PV_HD int wf_src_of(int e) {
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < W::LOG; ++i) s |= ((e >> i) & 1) << W::srcbit[i];
+    return s;
+}
+// butterfly-order index of source index s (inverse map)
+template <class W> PV_HD int wf_e_of_src(int s) {
+    int e = 0;
+#pragma unroll
+    for (int i = 0; i < W::LOG; ++i) e |= ((s >> W::srcbit[i]) & 1) << i;
+    return e;
+}
+template <class W> PV_HD int wf_lane_part(int pass, int lane) {
+    int e = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) e |= ((lane >> i) & 1) << W::lanepos[pass][i];
+    return e;
+}
+
+// ---- butterflies (kf_bfly4 kiss_fft.c:59-103, kf_bfly2 :36-57) --------------------------------
+template <bool INV> PV_HD void wf_bfly4(cf &f0, cf &f1, cf &f2, cf &f3, cf t1, cf t2, cf t3) {
+    const cf s0 = wf_cmul(f1, t1);
+    const cf s1 = wf_cmul(f2, t2);
+    const cf s2 = wf_cmul(f3, t3);
+    const cf s5 = wf_sub(f0, s1);
+    const cf g0 = wf_add(f0, s1);
+    const cf s3 = wf_add(s0, s2);
+    const cf s4 = wf_sub(s0, s2);
+    f2 = wf_sub(g0, s3);
+    f0 = wf_add(g0, s3);
+    if (INV) {
+        f1 = cf{s5.x - s4.y, s5.y + s4.x};
+        f3 = cf{s5.x + s4.y, s5.y - s4.x};
+    } else {
+        f1 = cf{s5.x + s4.y, s5.y - s4.x};
+        f3 = cf{s5.x - s4.y, s5.y + s4.x};
+    }
+}
+PV_HD void wf_bfly2(cf &f0, cf &f1, cf t) {
+    const cf u = wf_cmul(f1, t);
+    f1 = wf_sub(f0, u);
+    f0 = wf_add(f0, u);
+}
+
+// one butterfly stage S on the register array (lp = this lane's part of e in the stage's pass)
+template <class W, int S, bool INV> PV_HD void wf_stage(cf (&v)[W::R], int lp, const cf *__restrict__ tw) {
+    constexpr int pass = W::st_pass[S], eb = W::st_bit[S], radix = W::st_radix[S];
+    constexpr int m = 1 << eb;
+    constexpr int fs = W::N_C / (m * radix);
+    constexpr int p = wf_find_regbit<W>(pass, eb);
+    static_assert(p >= 0, "stage digit must live in registers in its pass");
+#pragma unroll
+    for (int r = 0; r < W::R; ++r) {
+        if ((r >> p) & (radix - 1)) continue;
+        const int k = (lp + wf_reg_part<W>(pass, r)) & (m - 1);
+        if (radix == 4) {
+            wf_bfly4<INV>(v[r], v[r + (1 << p)], v[r + (2 << p)], v[r + (3 << p)], tw[k * fs], tw[2 * k * fs],
+                          tw[3 * k * fs]);
+        } else {
+            wf_bfly2(v[r], v[r + (1 << p)], tw[k * fs]);
+        }
+    }
+}
+
+template <class W, int P, bool INV> PV_HD void wf_run_pass_stages(cf (&v)[W::R], int lp, const cf *__restrict__ tw) {
+    if (W::NSTAGE > 0 && W::st_pass[0] == P) wf_stage<W, 0, INV>(v, lp, tw);
+    if (W::NSTAGE > 1 && W::st_pass[1] == P) wf_stage<W, 1, INV>(v, lp, tw);
+    if (W::NSTAGE > 2 && W::st_pass[2] == P) wf_stage<W, 2, INV>(v, lp, tw);
+    if (W::NSTAGE > 3 && W::st_pass[3] == P) wf_stage<W, 3, INV>(v, lp, tw);
+    if (W::NSTAGE > 4 && W::st_pass[4] == P) wf_stage<W, 4, INV>(v, lp, tw);
+    if (W::NSTAGE > 5 && W::st_pass[5] == P) wf_stage<W, (W::NSTAGE > 5 ? 5 : 0), INV>(v, lp, tw);
+}
+
+template <class W, int P> PV_HD void wf_store(cf *lds, const cf (&v)[W::R], int lp) {
+#pragma unroll
+    for (int r = 0; r < W::R; ++r) lds[W::pad(lp | wf_reg_part<W>(P, r))] = v[r];
+}
+template <class W, int P> PV_HD void wf_load(const cf *lds, cf (&v)[W::R], int lp) {
+#pragma unroll
+    for (int r = 0; r < W::R; ++r) v[r] = lds[W::pad(lp | wf_reg_part<W>(P, r))];
+}
+
+// Pass P of the FFT for one lane.  P == 0 expects v already loaded in pass-0 layout (element
+// e = lane_part<0>(lane) | reg_part<0>(r)); passes 1 and 2 load their layout from LDS first.  Every pass
+// leaves its results in LDS at pad(e); after pass 2 the LDS region holds the transform in natural order.
+// The caller separates passes by a wave-level ordering point (all lanes finish pass P before pass P+1).
+template <class W, int P, bool INV> PV_HD void wf_fft_pass(cf (&v)[W::R], int lane, cf *lds, const cf *__restrict__ tw) {
+    const int lp = wf_lane_part<W>(P, lane);
+    if (P > 0) wf_load<W, P>(lds, v, lp);
+    wf_run_pass_stages<W, P, INV>(v, lp, tw);
+    wf_store<W, P>(lds, v, lp);
+}
+
+} // namespace pv
