@@ -289,7 +289,9 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     aa.tb = tb;
     aa.ia = ia;
     aa.hop = d.hop;
+    const int s0 = (int)(t0 % TR);
     aa.t0 = t0;
+    aa.s0 = s0;
     aa.Tn = Tn;
     aa.TR = TR;
     aa.rows = rows;
@@ -316,6 +318,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ma.Tn = Tn;
         ma.two_pi_hop = d.two_pi_hop;
         ma.t0 = t0;
+        ma.s0 = s0;
         ma.phase_inc = d_pinc;
         ma.phase = phase.p;
         ma.peaks = peaks.p;
@@ -337,6 +340,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         qa.Tn = Tn;
         qa.two_pi_hop = d.two_pi_hop;
         qa.t0 = t0;
+        qa.s0 = s0;
         qa.phase_inc = d_pinc;
         qa.phase = phase.p;
         qa.peaks = peaks.p;
@@ -363,6 +367,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         pa.Tn = Tn;
         pa.two_pi_hop = d.two_pi_hop;
         pa.t0 = t0;
+        pa.s0 = s0;
         pa.phase_inc = d_pinc;
         pa.phase = phase.p;
         pa.outphase = outphase.p;
@@ -385,6 +390,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     sa.robotic = d.robotic ? 1 : 0;
     sa.coremode = cm < 0 ? 0 : cm;
     sa.t0 = t0;
+    sa.s0 = s0;
     sa.Tn = Tn;
     sa.TR = TR;
     sa.rows = rows;
@@ -423,6 +429,9 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         oa.sinc = sinc.p;
         oa.sinc_len = d.resample ? (int)d.sinc.size() : 0;
         oa.lds_floats = ola_lds_floats;
+        oa.tab_bytes = !d.resample ? 0
+                       : d.interp  ? d.oversample * (d.filt_len + 1) * 16
+                                   : (int)((d.sinc.size() * sizeof(float) + 15) & ~(size_t)15);
         oa.out = out;
         oa.out_stride_row = out_stride_row;
         oa.k_base = k_base;

@@ -41,6 +41,7 @@ struct AnalyzeArgs {
     InAddr ia;
     int hop;
     int64_t t0; // first slice of this launch
+    int s0;     // ring slot of t0 (= t0 % TR, computed on the host: no 64-bit modulo in the kernels)
     int Tn;     // slices in this launch
     int TR;     // ring slots
     int rows;   // S*C
@@ -61,7 +62,7 @@ struct PeakRec {
 };
 
 struct MatchArgs {
-    int N, hs, HP, PKP, C, hop, TR, rows, Tn;
+    int N, hs, HP, PKP, C, hop, TR, rows, Tn, s0;
     double two_pi_hop;
     int64_t t0;
     const int32_t *phase_inc; // [Tn]
@@ -73,7 +74,7 @@ struct MatchArgs {
 };
 
 struct SeqArgs {
-    int N, hs, HP, PKP, C, hop, TR, rows, Tn;
+    int N, hs, HP, PKP, C, hop, TR, rows, Tn, s0;
     double two_pi_hop;
     int64_t t0;
     const int32_t *phase_inc;
@@ -92,7 +93,7 @@ struct SeqArgs {
 
 // coremode 0: per-bin recurrence, one thread per bin, streaming over the slices of the launch
 struct PropArgs {
-    int N, hs, HP, C, hop, TR, rows, Tn;
+    int N, hs, HP, C, hop, TR, rows, Tn, s0;
     double two_pi_hop;
     int64_t t0;
     const int32_t *phase_inc;
@@ -111,6 +112,7 @@ struct SynthArgs {
     int robotic;
     int coremode; // 0: phases from outphase; 1: per-step mode (rot / outphase); 2: phase * inc / hop
     int64_t t0;
+    int s0;
     int Tn, TR, rows, PKP;
     const int32_t *phase_inc;
     const float *mag;
@@ -151,6 +153,7 @@ struct OlaArgs {
     const float *sinc;
     int sinc_len;
     int lds_floats; // capacity of the OLA tile in LDS
+    int tab_bytes;  // LDS bytes of the resampler coefficient table (16-byte multiple)
     // output
     float *out;
     int64_t out_stride_row; // floats between consecutive (stream,channel) rows

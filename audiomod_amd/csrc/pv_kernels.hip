@@ -41,7 +41,23 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
+// princarg(a) = mod(a + pi, -2 pi) + pi with mod(x, y) = x - y*floor(x/y), in double (sys.h:84,91).
+// floor(x/y) needs the correctly rounded quotient only when x/y is within rounding distance of an integer;
+// otherwise floor(x * (1/y)) is the same integer (|x*(1/y) - x/y| <= 3.4e-16 |x/y|, far below the 1e-9
+// guard band), so the IEEE divide runs only on the rare lanes inside the guard band.  The returned value is
+// bit-identical to the reference expression in every case.
 __device__ __forceinline__ double princarg(double a) {
+    const double x = a + PV_PI;
+    const double y = -2.0 * PV_PI;
+    const double q = x * (1.0 / y);
+    double n = floor(q);
+    const double f = q - n;
+    if (!(f > 1e-9 && f < 1.0 - 1e-9)) n = floor(x / y);
+    return (x - (y * n)) + PV_PI;
+}
+
+// the plain reference expression (one IEEE divide): lower latency when a single dependent chain is all there is
+__device__ __forceinline__ double princarg_div(double a) {
     const double x = a + PV_PI;
     const double y = -2.0 * PV_PI;
     return (x - (y * floor(x / y))) + PV_PI;
@@ -49,6 +65,12 @@ __device__ __forceinline__ double princarg(double a) {
 
 // XCD-aware block -> (row, slice) map: blocks b and b+8 share an XCD (and its L2), so each XCD walks
 // whole rows (one stream-channel) slice after slice and re-reads the overlapping input from its own L2.
+__device__ __forceinline__ int ring_slot(int s0, int tl, int TR) {
+    const int s = s0 + tl; // tl < TR, so one conditional wrap is enough
+    return s >= TR ? s - TR : s;
+}
+__device__ __forceinline__ int ring_prev(int slot, int TR) { return slot == 0 ? TR - 1 : slot - 1; }
+
 __device__ __forceinline__ bool block_to_row_slice(int Tn, int rows, int &row, int &tl) {
     const int b = blockIdx.x;
     const int xcd = b & 7, q = b >> 3;
@@ -124,7 +146,7 @@ __global__ __launch_bounds__(kFftThreads) void pv_analyze_kernel(const AnalyzeAr
     int row, tl;
     if (!block_to_row_slice(a.Tn, a.rows, row, tl)) return;
     const int64_t t = a.t0 + tl;
-    const int slot = (int)(t % a.TR);
+    const int slot = ring_slot(a.s0, tl, a.TR);
     const int64_t a0 = t * (int64_t)a.hop;
     // row = s*Cch + c; the host guarantees stride_s == Cch*stride_c for contiguous rows
     const float *__restrict__ in = a.ia.in + (int64_t)row * a.ia.stride_c;
@@ -236,7 +258,7 @@ template <int NC> __global__ __launch_bounds__(256) void pv_analyze_wave_kernel(
     if (!block_to_row_slice4(a.Tn, a.rows, row, tl)) return; // wave-uniform
     const DevTables &tb = a.tb;
     const int64_t t = a.t0 + tl;
-    const int slot = (int)(t % a.TR);
+    const int slot = ring_slot(a.s0, tl, a.TR);
     const int64_t a0 = t * (int64_t)a.hop;
     const float *__restrict__ in = a.ia.in + (int64_t)row * a.ia.stride_c;
     const float *__restrict__ w = tb.window;
@@ -388,18 +410,25 @@ __global__ __launch_bounds__(kMatchThreads) void pv_match_kernel(const MatchArgs
     const int tl = blockIdx.x, row = blockIdx.y, nt = blockDim.x, tid = threadIdx.x;
     const int s = row / a.C, c = row - s * a.C;
     const int64_t t = a.t0 + tl;
-    const int slot = (int)(t % a.TR);
+    const int slot = ring_slot(a.s0, tl, a.TR), pslot = ring_prev(slot, a.TR);
     const int64_t plane = (int64_t)row * a.TR + slot;
     const int ncur = a.npk[plane];
     int64_t pplane = -1; // plane of the previous step
     if (c > 0) pplane = (int64_t)(row - 1) * a.TR + slot;
-    else if (t > 0) pplane = (int64_t)(s * a.C + a.C - 1) * a.TR + (int)((t - 1) % a.TR);
+    else if (t > 0) pplane = (int64_t)(s * a.C + a.C - 1) * a.TR + pslot;
     const int nprev = pplane >= 0 ? a.npk[pplane] : 0;
     const bool first = (t == 0 && c == 0);
     const int mode = first ? kModeInit : ((ncur == 0 || nprev == 0) ? kModeProp : kModeLock);
-    if (tid == 0) a.modes[plane] = mode;
+    if (tid == 0) {
+        a.modes[plane] = mode;
+        // step header in the (always free) last record slot: the sequential kernel fetches it with a vector
+        // load together with its peak record, one step ahead
+        PeakRec hdr{};
+        hdr.p1r1 = (uint32_t)mode | ((uint32_t)ncur << 2);
+        a.recs[plane * a.PKP + a.PKP - 1] = hdr;
+    }
     if (mode != kModeLock) return;
-    const int64_t splane = t > 0 ? (int64_t)row * a.TR + (int)((t - 1) % a.TR) : -1;
+    const int64_t splane = t > 0 ? (int64_t)row * a.TR + pslot : -1;
     const int nsame = splane >= 0 ? a.npk[splane] : 0;
     for (int i = tid; i < ncur; i += nt) scur[i] = a.peaks[plane * a.PKP + i];
     for (int i = tid; i < nprev; i += nt) sprev[i] = a.peaks[pplane * a.PKP + i];
@@ -493,21 +522,40 @@ __global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
     const float hop_f = (float)a.hop;
     const double Nd = (double)a.N;
 
+    // the step's inputs (mode, peak count, this lane's peak record) do not depend on the recurrence: they are
+    // fetched one step ahead so the global-load latency overlaps the previous step's princarg chain
+    const bool one_pass = a.PKP <= nt; // every peak has its own lane
+    auto plane_of = [&](int tl) { return (int64_t)row * a.TR + ring_slot(a.s0, tl, a.TR); };
+    // The header is wave-uniform, but it must come through the vector memory path: a scalar load shares its
+    // counter (lgkmcnt) with the LDS reads of the chain and would put its latency back on the critical path.
+    // An opaque zero in a VGPR keeps the compiler from scalarising the address.
+    int vz = 0;
+    asm volatile("" : "+v"(vz));
+    uint32_t hdr_n = a.recs[plane_of(0) * a.PKP + a.PKP - 1 + vz].p1r1;
+    // unconditional (index clamped): a load inside an exec-masked branch gets its s_waitcnt at the end of
+    // the branch, which would defeat the prefetch
+    const int rix = tid < a.PKP ? tid : a.PKP - 1;
+    PeakRec r_n = a.recs[plane_of(0) * a.PKP + rix];
+
     for (int tl = 0; tl < a.Tn; ++tl) {
         const int64_t t = a.t0 + tl;
-        const int slot = (int)(t % a.TR);
-        const int64_t plane = (int64_t)row * a.TR + slot;
-        const int mode = a.modes[plane];
+        const int64_t plane = plane_of(tl);
+        const int mode = (int)(hdr_n & 3u), n = (int)(hdr_n >> 2);
+        const PeakRec rc = r_n;
+        if (tl + 1 < a.Tn) {
+            const int64_t pn = plane_of(tl + 1);
+            hdr_n = a.recs[pn * a.PKP + a.PKP - 1 + vz].p1r1;
+            r_n = a.recs[pn * a.PKP + rix];
+        }
         if (mode == kModeLock) {
-            const int n = a.npk[plane];
             for (int p = tid; p < n; p += nt) {
-                const PeakRec r = a.recs[plane * a.PKP + p];
+                const PeakRec r = one_pass ? rc : a.recs[plane * a.PKP + p];
                 float po;
-                if (kind == 2) po = (float)princarg((double)(r.a1 + rprev[r.p1r1 >> 16]));
+                if (kind == 2) po = (float)princarg_div((double)(r.a1 + rprev[r.p1r1 >> 16]));
                 else if (kind == 1) po = spo[r.p1r1 & 0xffffu];
                 else po = 0.f;
-                const float tgt = (float)princarg((double)(po + r.adv));
-                const float rt = (float)princarg((double)(tgt - r.a2));
+                const float tgt = (float)princarg_div((double)(po + r.adv));
+                const float rt = (float)princarg_div((double)(tgt - r.a2));
                 rcur[p] = rt;
                 a.rot[plane * a.PKP + p] = rt;
             }
@@ -518,7 +566,7 @@ __global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
         } else {
             // per-bin path; first materialise prev_out when the previous step of this row was locked
             const float *__restrict__ A = a.phase + plane * a.HP;
-            const int64_t splane = t > 0 ? (int64_t)row * a.TR + (int)((t - 1) % a.TR) : -1;
+            const int64_t splane = t > 0 ? (int64_t)row * a.TR + ring_prev(ring_slot(a.s0, tl, a.TR), a.TR) : -1;
             const float *__restrict__ Ap = splane >= 0 ? a.phase + splane * a.HP : nullptr;
             int nsame = 0;
             if (kind == 2) {
@@ -585,7 +633,7 @@ __global__ __launch_bounds__(kPropThreads) void pv_prop_kernel(const PropArgs a)
     const float hop_f = (float)a.hop;
     for (int tl = 0; tl < a.Tn; ++tl) {
         const int64_t t = a.t0 + tl;
-        const int64_t plane = (int64_t)row * a.TR + (int)(t % a.TR);
+        const int64_t plane = (int64_t)row * a.TR + ring_slot(a.s0, tl, a.TR);
         const float phi = a.phase[plane * a.HP + i];
         float outv;
         if (t == 0 && c == 0) {
@@ -624,7 +672,7 @@ __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a
     int row, tl;
     if (!block_to_row_slice(a.Tn, a.rows, row, tl)) return;
     const int64_t t = a.t0 + tl;
-    const int64_t plane = (int64_t)row * a.TR + (int)(t % a.TR);
+    const int64_t plane = (int64_t)row * a.TR + ring_slot(a.s0, tl, a.TR);
     const float *__restrict__ mag = a.mag + plane * tb.HP;
     const float *__restrict__ A = a.phase + plane * tb.HP;
     const double Nd = (double)N;
@@ -730,7 +778,7 @@ template <int NC> __global__ __launch_bounds__(256) void pv_synth_wave_kernel(co
     if (!block_to_row_slice4(a.Tn, a.rows, row, tl)) return; // wave-uniform
     const DevTables &tb = a.tb;
     const int64_t t = a.t0 + tl;
-    const int64_t plane = (int64_t)row * a.TR + (int)(t % a.TR);
+    const int64_t plane = (int64_t)row * a.TR + ring_slot(a.s0, tl, a.TR);
     const float *__restrict__ mag = a.mag + plane * tb.HP;
     const float *__restrict__ A = a.phase + plane * tb.HP;
     const cf *__restrict__ tw = reinterpret_cast<const cf *>(tb.tw_inv);
@@ -754,16 +802,35 @@ template <int NC> __global__ __launch_bounds__(256) void pv_synth_wave_kernel(co
     } else {
         const int mode = a.coremode == 1 ? a.modes[plane] : kModeProp;
         if (mode == kModeLock) {
+            // region(k) = number of region boundaries <= k.  Boundaries go into a bitmap (one 64-bit word per
+            // 64 bins = per value of j), so the lookup is a prefix count + one masked popcount per bin.
             const int n = a.npk[plane];
+            unsigned int *bits32 = reinterpret_cast<unsigned int *>(spk + a.PKP); // [2 * JB]
+            int *pre = reinterpret_cast<int *>(bits32 + 2 * JB);                  // [JB]
             for (int i = lane; i < n; i += 64) {
                 spk[i] = a.peaks[plane * a.PKP + i];
                 srot[i] = a.rot[plane * a.PKP + i];
             }
+            if (lane < 2 * JB) bits32[lane] = 0u;
             wave_sync();
+            for (int i = lane; i + 1 < n; i += 64) {
+                const int b = ((int)spk[i] + (int)spk[i + 1] + 1) >> 1; // round(x.5) away from zero (:676-682)
+                atomicOr(&bits32[b >> 5], 1u << (b & 31));
+            }
+            wave_sync();
+            const unsigned long long *bits = reinterpret_cast<const unsigned long long *>(bits32);
+            if (lane < JB) {
+                int acc = 0;
+                for (int i = 0; i < lane; ++i) acc += __popcll(bits[i]);
+                pre[lane] = acc;
+            }
+            wave_sync();
+            const unsigned long long lemask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
 #pragma unroll 4
             for (int j = 0; j < JB; ++j) {
                 const int k = lane + 64 * j;
-                sph[k] = (float)princarg((double)(A[k] + srot[region_of(spk, n, k)]));
+                const int reg = pre[j] + __popcll(bits[j] & lemask);
+                sph[k] = (float)princarg((double)(A[k] + srot[reg]));
             }
         } else {
             const float *__restrict__ op = a.outphase + plane * tb.HP;
@@ -918,40 +985,58 @@ void launch_synth(const SynthArgs &a, hipStream_t st) {
 // --------------------------------------------------------------------------------------------
 // overlap-add + normalise + resample
 // --------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(kTileOut) void pv_ola_kernel(const OlaArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float *ola = reinterpret_cast<float *>(smem_raw);           // [lds_floats]
-    float *stab = ola + a.lds_floats;                           // [sinc_len]
-    int *sP = reinterpret_cast<int *>(stab + a.sinc_len);       // [kMaxTileFrames] P_t - n_lo
+    // interpolated mode: coefficient table expanded per sub-sample offset, tab4[off][j] = the four taps
+    // sinc[4 + (j+1)*ov - off + {-2,-1,0,1}] of resampler_basic_interpolate_single (resample.c:494-535) as one
+    // aligned float4; rows are padded to NF+1 slots so the (at most ov) distinct rows a wave reads in one
+    // ds_read_b128 land on different banks.  direct mode: the sinc table as it is.
+    float4 *tab4 = reinterpret_cast<float4 *>(smem_raw);
+    float *stab = reinterpret_cast<float *>(smem_raw);
+    float *ola = reinterpret_cast<float *>(smem_raw + a.tab_bytes);   // [lds_floats]
+    int *sP = reinterpret_cast<int *>(ola + a.lds_floats);            // [kMaxTileFrames] P_t - n_lo
     const int tile_i = blockIdx.x, row = blockIdx.y, nt = blockDim.x, tid = threadIdx.x;
     const OlaTile tile = a.tiles[tile_i];
-    const int N = a.N;
+    const int N = a.N, NF = a.filt_len;
 
     if (tid < tile.t_cnt) sP[tid] = (int)(a.P[tile.p_off + tid] - tile.n_lo);
-    if (a.resample)
-        for (int i = tid; i < a.sinc_len; i += nt) stab[i] = a.sinc[i];
+    if (a.resample) {
+        if (a.interp) {
+            const int ov = a.oversample;
+            for (int idx = tid; idx < ov * NF; idx += nt) {
+                const int off = idx / NF, j = idx - off * NF;
+                const float *sp = a.sinc + 4 + (j + 1) * ov - off - 2;
+                tab4[off * (NF + 1) + j] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            }
+        } else {
+            for (int i = tid; i < a.sinc_len; i += nt) stab[i] = a.sinc[i];
+        }
+    }
     __syncthreads();
 
     // y[n] = (sum_t frame_t[n - P_t]) / (delta[n] + sum_t gain*w[n - P_t]), ascending t, starting from 0.0f
-    // (== outputAccumulator / windowAccumulator at the moment writeSlice divides them)
+    // (== outputAccumulator / windowAccumulator at the moment writeSlice divides them).  Frames that do not
+    // cover n contribute an exact +0.0f (adding +0 never changes a sum that started at +0), so the loads are
+    // unconditional on a clamped address: no divergent branch, and the compiler can batch them.
     const float *__restrict__ fr = a.frames + (int64_t)row * a.FR * N;
+    const float *__restrict__ win = a.window;
     for (int i = tid; i < tile.n_cnt; i += nt) {
         const int64_t n = tile.n_lo + i;
-        float y = 0.f;
-        if (n >= 0) {
-            float acc = 0.f;
-            float wacc = n == 0 ? 1.f : 0.f;
-            for (int j = 0; j < tile.t_cnt; ++j) {
-                const int off = i - sP[j]; // n - P_t
-                if (off >= 0 && off < N) {
-                    const int slot = (tile.t_first + j) & (a.FR - 1);
-                    acc += fr[(int64_t)slot * N + off];
-                    wacc += a.window[off] * a.win_gain;
-                }
-            }
-            y = acc / wacc;
+        float acc = 0.f;
+        float wacc = n == 0 ? 1.f : 0.f;
+        for (int j = 0; j < tile.t_cnt; ++j) {
+            const int off = i - sP[j]; // n - P_t
+            const bool in = off >= 0 && off < N;
+            const int oc = in ? off : 0;
+            const int slot = (tile.t_first + j) & (a.FR - 1);
+            const float fv = fr[(int64_t)slot * N + oc];
+            const float wv = win[oc];
+            acc += in ? fv : 0.f;
+            wacc += in ? wv * a.win_gain : 0.f;
         }
-        ola[i] = y;
+        ola[i] = n >= 0 ? acc / wacc : 0.f;
     }
     __syncthreads();
 
@@ -965,40 +1050,42 @@ __global__ __launch_bounds__(kTileOut) void pv_ola_kernel(const OlaArgs a) {
     // position of output k in the OLA stream: last_sample = filt_len/2 + floor(k*num/den),
     // samp_frac_num = (k*num) mod den  (closed form of resample.c:548-554 from skip_zeros :1225)
     const unsigned long long tot = (unsigned long long)k * a.num;
-    const int64_t pos = (int64_t)(a.filt_len / 2) + (int64_t)(tot / a.den);
+    const int64_t pos = (int64_t)(NF / 2) + (int64_t)(tot / a.den);
     const uint32_t frac_num = (uint32_t)(tot % a.den);
-    const int i0 = (int)(pos - a.filt_len + 1 - tile.n_lo); // LDS index of tap j = 0
-    const int NF = a.filt_len;
+    const float *x = ola + (int)(pos - NF + 1 - tile.n_lo); // tap j = 0
     if (a.interp) {
         const uint32_t ov = (uint32_t)a.oversample;
         const int offset = (int)(frac_num * ov / a.den);
         const float frac = ((float)((frac_num * ov) % a.den)) / a.den;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        const float *t = stab + 4 + (int)ov - offset; // tap j reads t[j*ov - 2 .. j*ov + 1]
-        for (int j = 0; j < NF; ++j) {
-            const float x = ola[i0 + j];
-            const float *tj = t + j * (int)ov;
-            a0 += x * tj[-2];
-            a1 += x * tj[-1];
-            a2 += x * tj[0];
-            a3 += x * tj[1];
+        const float4 *__restrict__ T = tab4 + offset * (NF + 1);
+        v2f a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll 8
+        for (int j = 0; j < NF; ++j) { // NF is a multiple of 4 (resample.c:687)
+            const float xv = x[j];
+            const float4 c = T[j];
+            const v2f xx = {xv, xv};
+            const v2f c01 = {c.x, c.y}, c23 = {c.z, c.w};
+            a01 += xx * c01; // -ffp-contract=off: separate multiply and add, per element, like the reference
+            a23 += xx * c23;
         }
         // cubic_coef (resample.c:339-351)
         const float c0 = -0.16667f * frac + 0.16667f * frac * frac * frac;
         const float c1 = frac + 0.5f * frac * frac - 0.5f * frac * frac * frac;
         const float c3 = -0.33333f * frac + 0.5f * frac * frac - 0.16667f * frac * frac * frac;
         const float c2 = (float)(1. - c0 - c1 - c3);
-        *out = (c0 * a0) + (c1 * a1) + (c2 * a2) + (c3 * a3);
+        *out = (c0 * a01.x) + (c1 * a01.y) + (c2 * a23.x) + (c3 * a23.y);
     } else {
         float sum = 0.f;
         const float *t = stab + frac_num * (uint32_t)NF;
-        for (int j = 0; j < NF; ++j) sum += ola[i0 + j] * t[j];
+        for (int j = 0; j < NF; ++j) sum += x[j] * t[j];
         *out = sum;
     }
 }
 
 void launch_ola(const OlaArgs &a, hipStream_t st) {
-    const size_t lds = sizeof(float) * ((size_t)a.lds_floats + a.sinc_len) + sizeof(int) * kMaxTileFrames;
+    const size_t lds = (size_t)a.tab_bytes + sizeof(float) * (size_t)a.lds_floats + sizeof(int) * kMaxTileFrames;
+    static bool big = false;
+    allow_big_lds(pv_ola_kernel, big);
     hipLaunchKernelGGL(pv_ola_kernel, dim3(a.ntiles, a.rows), dim3(kTileOut), lds, st, a);
 }
 

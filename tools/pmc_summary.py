@@ -12,7 +12,7 @@ def main():
     for d in sys.argv[1:]:
         for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                k = r["Kernel_Name"].split("(")[0].replace("pv::", "")
+                k = r["Kernel_Name"].split("(")[0].replace("pv::", "").replace("void ", "")
                 if not k.startswith("pv_"):
                     continue
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
