@@ -106,6 +106,7 @@ struct Core {
     DevBuf<int32_t> perm, iperm;
     DevBuf<float2> tw_fwd, tw_inv, st_fwd, st_inv;
     DevBuf<float> window, sinc;
+    DevBuf<float4> tab4;
     DevBuf<float> mag, phase, outphase, frames, rot;
     DevBuf<uint16_t> peaks;
     DevBuf<int32_t> npk, modes;
@@ -118,9 +119,10 @@ struct Core {
     int reset_state(hipStream_t st);
     // tile geometry for outputs [ka, kb) given the slice table (P of slice t = slices[t - t_base].P)
     int build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64_t t_end, int64_t ka, int64_t kb,
-                    int32_t p_index_base, std::vector<OlaTile> &tiles) const;
+                    int32_t p_index_base, std::vector<OlaTile> &tiles, std::vector<float> &wacc) const;
     void launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
-                      int ntiles, const int64_t *d_P, float *out, int64_t out_stride_row, int64_t k_base,
+                      int ntiles, const int64_t *d_P, const float *d_wacc, float *out, int64_t out_stride_row,
+                      int64_t k_base,
                       hipStream_t st, hipEvent_t *ev /* 2*PV_NUM_KERNELS events or null */) const;
 };
 
@@ -180,6 +182,21 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     if ((st = up2(st_inv, d.fft.st_inv)) != PV_OK) return st;
     if ((st = window.upload(d.window)) != PV_OK) return st;
     if ((st = sinc.upload(d.sinc)) != PV_OK) return st;
+    {
+        // interpolated-sinc coefficients expanded per sub-sample offset: row `off`, tap j = the four table
+        // entries sinc[4 + (j+1)*ov - off + {-2,-1,0,1}] that resampler_basic_interpolate_single multiplies
+        // into its four accumulators (resample.c:494-535); rows padded to filt_len + 1 (LDS bank spread)
+        std::vector<float4> t4;
+        if (d.resample && d.interp) {
+            t4.assign((size_t)d.oversample * (d.filt_len + 1), make_float4(0, 0, 0, 0));
+            for (int off = 0; off < d.oversample; ++off)
+                for (int j = 0; j < d.filt_len; ++j) {
+                    const float *sp = d.sinc.data() + 4 + (j + 1) * d.oversample - off - 2;
+                    t4[(size_t)off * (d.filt_len + 1) + j] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                }
+        }
+        if ((st = tab4.upload(t4)) != PV_OK) return st;
+    }
 
     tb.N = d.N;
     tb.hs = d.hs;
@@ -231,7 +248,7 @@ int Core::reset_state(hipStream_t st) {
 }
 
 int Core::build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64_t t_end, int64_t ka, int64_t kb,
-                      int32_t p_index_base, std::vector<OlaTile> &tiles) const {
+                      int32_t p_index_base, std::vector<OlaTile> &tiles, std::vector<float> &wacc) const {
     // slices[t - t_base] must exist for every t in [max(t_base, t_end - FR), t_end); a tile that needed an
     // older frame would be rejected below anyway (the frame ring no longer holds it)
     int64_t t_lo = t_end - FR > t_base ? t_end - FR : t_base; // monotone cursors
@@ -274,12 +291,27 @@ int Core::build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64
         }
         tl.p_off = (int32_t)(t_lo - p_index_base);
         tiles.push_back(tl);
+        // window-sum denominator of every OLA sample of the tile: windowAccumulator at the moment writeSlice
+        // divides (channelinfo.cc:108 seeds [0] with 1; synthesiseSlice :1073 adds w[i] * float(area*1.5) per
+        // frame, ascending t).  Float arithmetic, evaluated exactly as written (-ffp-contract=off).
+        const size_t wbase = wacc.size();
+        wacc.resize(wbase + (size_t)ola_lds_floats, 1.0f);
+        for (int i = 0; i < tl.n_cnt; ++i) {
+            const int64_t n = n_lo + i;
+            float acc = n == 0 ? 1.f : 0.f;
+            for (int64_t t = t_lo; t <= t_hi; ++t) {
+                const int64_t off = n - slices[(size_t)(t - t_base)].P;
+                if (off >= 0 && off < d.N) acc += d.window[(size_t)off] * d.win_gain;
+            }
+            wacc[wbase + (size_t)i] = acc;
+        }
     }
     return PV_OK;
 }
 
 void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
-                        int ntiles, const int64_t *d_P, float *out, int64_t out_stride_row, int64_t k_base,
+                        int ntiles, const int64_t *d_P, const float *d_wacc, float *out, int64_t out_stride_row,
+                        int64_t k_base,
                         hipStream_t st, hipEvent_t *ev) const {
     const int cm = d.robotic ? -1 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
     auto rec = [&](int i) {
@@ -415,8 +447,6 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         oa.rows = rows;
         oa.FR = FR;
         oa.frames = frames.p;
-        oa.window = window.p;
-        oa.win_gain = d.win_gain;
         oa.tiles = d_tiles;
         oa.P = d_P;
         oa.ntiles = ntiles;
@@ -427,6 +457,8 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         oa.filt_len = d.filt_len;
         oa.oversample = d.oversample;
         oa.sinc = sinc.p;
+        oa.tab4 = tab4.p;
+        oa.wacc = d_wacc;
         oa.sinc_len = d.resample ? (int)d.sinc.size() : 0;
         oa.lds_floats = ola_lds_floats;
         oa.tab_bytes = !d.resample ? 0
@@ -484,8 +516,10 @@ struct pv_batch {
     DevBuf<int32_t> d_pinc;
     DevBuf<int64_t> d_P;
     DevBuf<OlaTile> d_tiles;
-    bool timing = false;
-    std::vector<hipEvent_t> ev_pool; // kEvPerChunk per chunk when timing
+    DevBuf<float> d_wacc;
+    int timing = 0; // 0 = off, n = instrument every n-th chunk
+    std::vector<hipEvent_t> ev_pool; // kEvPerChunk per instrumented chunk
+    std::vector<int> ev_chunk;       // chunk index of each used pool segment
     size_t ev_used = 0;
     double acc_ms[PV_NUM_KERNELS] = {};
     int64_t acc_n[PV_NUM_KERNELS] = {};
@@ -586,6 +620,7 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
         P[(size_t)t] = sl[(size_t)t].P;
     }
     std::vector<OlaTile> tiles;
+    std::vector<float> wacc;
     for (int64_t t0 = 0; t0 < T; t0 += Tc) {
         pv_batch::Chunk ch;
         ch.t0 = t0;
@@ -597,7 +632,7 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
         if (kb > b->plan.out_frames) kb = b->plan.out_frames;
         ch.tile_begin = (int)tiles.size();
         if (kb > ka) {
-            st = c.build_tiles(sl, 0, t1, ka, kb, 0, tiles);
+            st = c.build_tiles(sl, 0, t1, ka, kb, 0, tiles, wacc);
             if (st != PV_OK) return st;
         }
         ch.ntiles = (int)tiles.size() - ch.tile_begin;
@@ -606,6 +641,7 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
     if ((st = b->d_pinc.upload(pinc)) != PV_OK) return st;
     if ((st = b->d_P.upload(P)) != PV_OK) return st;
     if ((st = b->d_tiles.upload(tiles)) != PV_OK) return st;
+    if ((st = b->d_wacc.upload(wacc)) != PV_OK) return st;
     *out = b.release();
     return PV_OK;
 }
@@ -614,6 +650,7 @@ void pv_batch_destroy(pv_batch *b) { delete b; }
 
 int64_t pv_batch_out_frames(const pv_batch *b) { return b ? b->plan.out_frames : -1; }
 int64_t pv_batch_slices(const pv_batch *b) { return b ? (int64_t)b->plan.slices.size() : -1; }
+int32_t pv_batch_launches(const pv_batch *b) { return b ? (int32_t)b->chunks.size() : -1; }
 
 int pv_batch_get_info(const pv_batch *b, pv_info *info) {
     if (!b || !info) return PV_ERR_INVALID_ARG;
@@ -623,7 +660,8 @@ int pv_batch_get_info(const pv_batch *b, pv_info *info) {
 
 int pv_batch_enable_timing(pv_batch *b, int on) {
     if (!b) return PV_ERR_INVALID_ARG;
-    b->timing = on != 0;
+    b->timing = on < 0 ? 0 : on;
+    b->ev_chunk.clear();
     for (int k = 0; k < PV_NUM_KERNELS; ++k) {
         b->acc_ms[k] = 0;
         b->acc_n[k] = 0;
@@ -645,25 +683,26 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
     ia.stride_s = b->frames * c.C;
     ia.mask = ~0ull;
     ia.len = b->frames;
-    size_t ev_base = 0;
-    if (b->timing) {
-        // each timed run takes a fresh segment of the event pool; pv_batch_kernel_times folds and resets
-        ev_base = b->ev_used;
-        const size_t need = ev_base + b->chunks.size() * kEvPerChunk;
-        while (b->ev_pool.size() < need) {
-            hipEvent_t e;
-            HIPC(hipEventCreate(&e));
-            b->ev_pool.push_back(e);
-        }
-    }
+    // Instrumentation: HIP events around each kernel of every `timing`-th chunk.  An event record costs a few
+    // microseconds of stream time, so instrumenting every launch would slow the run it measures by ~10 %.
     size_t ci = 0;
     for (const auto &ch : b->chunks) {
-        hipEvent_t *ev = b->timing ? &b->ev_pool[ev_base + ci * kEvPerChunk] : nullptr;
+        hipEvent_t *ev = nullptr;
+        if (b->timing > 0 && (int)(ci % (size_t)b->timing) == (b->timing / 2) % b->timing) {
+            const size_t need = b->ev_used + kEvPerChunk;
+            while (b->ev_pool.size() < need) {
+                hipEvent_t e;
+                HIPC(hipEventCreate(&e));
+                b->ev_pool.push_back(e);
+            }
+            ev = &b->ev_pool[b->ev_used];
+            b->ev_used = need;
+            b->ev_chunk.push_back((int)ci);
+        }
         c.launch_chunk(ia, ch.t0, ch.Tn, b->d_pinc.p + ch.t0, b->d_tiles.p + ch.tile_begin, ch.ntiles, b->d_P.p,
-                       d_out, b->plan.out_frames, 0, st, ev);
+                       b->d_wacc.p + (size_t)ch.tile_begin * c.ola_lds_floats, d_out, b->plan.out_frames, 0, st, ev);
         ++ci;
     }
-    if (b->timing) b->ev_used = ev_base + b->chunks.size() * kEvPerChunk;
     HIPC(hipGetLastError());
     return PV_OK;
 }
@@ -674,7 +713,7 @@ int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launch
     const Derived &d = b->core.d;
     const int cm = d.robotic ? -1 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
     for (size_t i = 0; i + kEvPerChunk <= b->ev_used; i += kEvPerChunk) {
-        const auto &ch = b->chunks[(i / kEvPerChunk) % b->chunks.size()];
+        const auto &ch = b->chunks[(size_t)b->ev_chunk[i / kEvPerChunk]];
         for (int k = 0; k < PV_NUM_KERNELS; ++k) {
             if ((k == PV_K_MATCH || k == PV_K_SEQ) && cm != 1) continue;
             if (k == PV_K_PROP && cm != 0) continue;
@@ -687,6 +726,7 @@ int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launch
         }
     }
     b->ev_used = 0;
+    b->ev_chunk.clear();
     for (int k = 0; k < PV_NUM_KERNELS; ++k) {
         if (ms) ms[k] = b->acc_ms[k];
         if (launches) launches[k] = b->acc_n[k];
@@ -716,7 +756,7 @@ int pv_create(const pv_config *cfg, int device, pv_engine **out) {
     e->out_cap = (int)(kStreamChunk * per_slice) + 64;
     if ((st = e->d_out.alloc((size_t)c.C * e->out_cap)) != PV_OK) return st;
     if ((st = e->h_out.alloc((size_t)c.C * e->out_cap)) != PV_OK) return st;
-    const size_t desc_bytes = 16384;
+    const size_t desc_bytes = 256 * 1024;
     if ((st = e->d_desc.alloc(desc_bytes)) != PV_OK) return st;
     if ((st = e->h_desc.alloc(desc_bytes)) != PV_OK) return st;
     e->outq.resize(c.C);
@@ -780,8 +820,9 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         const SliceRec &last = e->recent[(size_t)(tb - 1 - e->t_base)];
         const int64_t ka = first.K0, kb = last.K0 + last.cnt;
         std::vector<OlaTile> tiles;
+        std::vector<float> wacc;
         if (kb > ka) {
-            st = c.build_tiles(e->recent, e->t_base, tb, ka, kb, (int32_t)e->t_base, tiles);
+            st = c.build_tiles(e->recent, e->t_base, tb, ka, kb, (int32_t)e->t_base, tiles, wacc);
             if (st != PV_OK) return st;
         }
         if (kb - ka > e->out_cap) {
@@ -800,7 +841,10 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         off += (nP * 8 + 15) & ~(size_t)15;
         const size_t t_off_bytes = off;
         memcpy(hd + off, tiles.data(), tiles.size() * sizeof(OlaTile));
-        off += tiles.size() * sizeof(OlaTile);
+        off += (tiles.size() * sizeof(OlaTile) + 15) & ~(size_t)15;
+        const size_t w_off_bytes = off;
+        if (off + wacc.size() * sizeof(float) <= e->h_desc.n) memcpy(hd + off, wacc.data(), wacc.size() * sizeof(float));
+        off += wacc.size() * sizeof(float);
         if (off > e->h_desc.n) {
             g_last_error = "internal: descriptor staging too small";
             return PV_ERR_UNSUPPORTED;
@@ -815,7 +859,8 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         ia.len = INT64_MAX;
         c.launch_chunk(ia, ta, Tn, reinterpret_cast<const int32_t *>(e->d_desc.p),
                        reinterpret_cast<const OlaTile *>(e->d_desc.p + t_off_bytes), (int)tiles.size(),
-                       reinterpret_cast<const int64_t *>(e->d_desc.p + p_off_bytes), e->d_out.p, e->out_cap, ka,
+                       reinterpret_cast<const int64_t *>(e->d_desc.p + p_off_bytes),
+                       reinterpret_cast<const float *>(e->d_desc.p + w_off_bytes), e->d_out.p, e->out_cap, ka,
                        e->stream, nullptr);
         (void)p_off_bytes;
         const int64_t cnt = kb - ka;

@@ -141,8 +141,6 @@ struct OlaTile {
 struct OlaArgs {
     int N, rows, FR;
     const float *frames;
-    const float *window;
-    float win_gain;
     const OlaTile *tiles;
     const int64_t *P; // OLA positions of candidate slices, indexed tile.p_off + j
     int ntiles;
@@ -152,6 +150,8 @@ struct OlaArgs {
     int filt_len, oversample;
     const float *sinc;
     int sinc_len;
+    const float4 *tab4; // interpolated mode: [oversample][filt_len + 1] expanded coefficient rows
+    const float *wacc;  // [ntiles][lds_floats] window-sum denominators of each tile's OLA samples
     int lds_floats; // capacity of the OLA tile in LDS
     int tab_bytes;  // LDS bytes of the resampler coefficient table (16-byte multiple)
     // output

@@ -526,30 +526,65 @@ __global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
     // fetched one step ahead so the global-load latency overlaps the previous step's princarg chain
     const bool one_pass = a.PKP <= nt; // every peak has its own lane
     auto plane_of = [&](int tl) { return (int64_t)row * a.TR + ring_slot(a.s0, tl, a.TR); };
+    // (one_pass: every peak has its own lane)
     // The header is wave-uniform, but it must come through the vector memory path: a scalar load shares its
     // counter (lgkmcnt) with the LDS reads of the chain and would put its latency back on the critical path.
     // An opaque zero in a VGPR keeps the compiler from scalarising the address.
     int vz = 0;
     asm volatile("" : "+v"(vz));
-    uint32_t hdr_n = a.recs[plane_of(0) * a.PKP + a.PKP - 1 + vz].p1r1;
     // unconditional (index clamped): a load inside an exec-masked branch gets its s_waitcnt at the end of
     // the branch, which would defeat the prefetch
     const int rix = tid < a.PKP ? tid : a.PKP - 1;
-    PeakRec r_n = a.recs[plane_of(0) * a.PKP + rix];
+    // prefetch one step ahead (deeper queues measured slower: the chain, not the load latency, bounds a step)
+    constexpr int kDepth = 1;
+    auto ld_hdr = [&](int tl) -> uint32_t { // always loads (clamped): keeps the VMEM count per iteration static
+        const uint32_t v = a.recs[plane_of(tl < a.Tn ? tl : a.Tn - 1) * a.PKP + a.PKP - 1 + vz].p1r1;
+        return tl < a.Tn ? v : 3u; // 3 = sentinel, ends the loops
+    };
+    auto ld_rec = [&](int tl) -> PeakRec { return a.recs[plane_of(tl < a.Tn ? tl : a.Tn - 1) * a.PKP + rix]; };
+    uint32_t h0 = ld_hdr(0);
+    PeakRec q0 = ld_rec(0);
 
-    for (int tl = 0; tl < a.Tn; ++tl) {
+    int tl = 0;
+    while (tl < a.Tn) {
+        // ---- fast inner loop: consecutive phase-locked steps.  It contains exactly two prefetch loads followed
+        // by one store per iteration, so the loop-top wait can be the counted vmcnt(1) (the store stays in
+        // flight); the slow per-bin path lives outside this loop precisely to keep that count static.
+        while (tl < a.Tn && (h0 & 3u) == (uint32_t)kModeLock && one_pass) {
+            const int64_t plane = plane_of(tl);
+            const PeakRec r = q0;
+            // fetch the next step (two loads, always)
+            h0 = ld_hdr(tl + kDepth);
+            q0 = ld_rec(tl + kDepth);
+            // Branch-free over the lanes: lanes beyond the peak count run on whatever their (clamped) record
+            // slot holds and write slots nobody reads.
+            const uint32_t r1 = min(r.p1r1 >> 16, (uint32_t)(a.PKP - 1));
+            const uint32_t p1 = (r.p1r1 & 0xffffu) & (uint32_t)(hs - 1);
+            float po;
+            if (kind == 2) po = (float)princarg((double)(r.a1 + rprev[r1]));
+            else if (kind == 1) po = spo[p1];
+            else po = 0.f;
+            const float tgt = (float)princarg((double)(po + r.adv));
+            const float rt = (float)princarg((double)(tgt - r.a2));
+            rcur[rix] = rt;
+            a.rot[plane * a.PKP + rix] = rt;
+            kind = 2;
+            float *tmp = rprev;
+            rprev = rcur;
+            rcur = tmp;
+            ++tl;
+            __syncthreads();
+        }
+        if (tl >= a.Tn) break;
+        // ---- general step (first slice, no-peak steps, or more peaks than lanes)
         const int64_t t = a.t0 + tl;
         const int64_t plane = plane_of(tl);
-        const int mode = (int)(hdr_n & 3u), n = (int)(hdr_n >> 2);
-        const PeakRec rc = r_n;
-        if (tl + 1 < a.Tn) {
-            const int64_t pn = plane_of(tl + 1);
-            hdr_n = a.recs[pn * a.PKP + a.PKP - 1 + vz].p1r1;
-            r_n = a.recs[pn * a.PKP + rix];
-        }
+        const int mode = (int)(h0 & 3u), n = (int)(h0 >> 2);
+        h0 = ld_hdr(tl + kDepth);
+        q0 = ld_rec(tl + kDepth);
         if (mode == kModeLock) {
             for (int p = tid; p < n; p += nt) {
-                const PeakRec r = one_pass ? rc : a.recs[plane * a.PKP + p];
+                const PeakRec r = a.recs[plane * a.PKP + p];
                 float po;
                 if (kind == 2) po = (float)princarg_div((double)(r.a1 + rprev[r.p1r1 >> 16]));
                 else if (kind == 1) po = spo[r.p1r1 & 0xffffu];
@@ -598,6 +633,7 @@ __global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
             }
             kind = 1;
         }
+        ++tl;
         __syncthreads();
     }
     if (kind == 2)
@@ -1004,12 +1040,8 @@ __global__ __launch_bounds__(kTileOut) void pv_ola_kernel(const OlaArgs a) {
     if (tid < tile.t_cnt) sP[tid] = (int)(a.P[tile.p_off + tid] - tile.n_lo);
     if (a.resample) {
         if (a.interp) {
-            const int ov = a.oversample;
-            for (int idx = tid; idx < ov * NF; idx += nt) {
-                const int off = idx / NF, j = idx - off * NF;
-                const float *sp = a.sinc + 4 + (j + 1) * ov - off - 2;
-                tab4[off * (NF + 1) + j] = make_float4(sp[0], sp[1], sp[2], sp[3]);
-            }
+            const int cnt = a.oversample * (NF + 1);
+            for (int i = tid; i < cnt; i += nt) tab4[i] = a.tab4[i];
         } else {
             for (int i = tid; i < a.sinc_len; i += nt) stab[i] = a.sinc[i];
         }
@@ -1017,26 +1049,24 @@ __global__ __launch_bounds__(kTileOut) void pv_ola_kernel(const OlaArgs a) {
     __syncthreads();
 
     // y[n] = (sum_t frame_t[n - P_t]) / (delta[n] + sum_t gain*w[n - P_t]), ascending t, starting from 0.0f
-    // (== outputAccumulator / windowAccumulator at the moment writeSlice divides them).  Frames that do not
-    // cover n contribute an exact +0.0f (adding +0 never changes a sum that started at +0), so the loads are
+    // (== outputAccumulator / windowAccumulator at the moment writeSlice divides them).  The denominator is
+    // data-independent: the host planner evaluates it once per tile with the same float arithmetic
+    // (pv_engine.cc build_tiles) and every (stream, channel) row reuses it.  Frames that do not cover n
+    // contribute an exact +0.0f (adding +0 never changes a sum that started at +0), so the loads are
     // unconditional on a clamped address: no divergent branch, and the compiler can batch them.
     const float *__restrict__ fr = a.frames + (int64_t)row * a.FR * N;
-    const float *__restrict__ win = a.window;
+    const float *__restrict__ wacc = a.wacc + (int64_t)tile_i * a.lds_floats;
     for (int i = tid; i < tile.n_cnt; i += nt) {
-        const int64_t n = tile.n_lo + i;
         float acc = 0.f;
-        float wacc = n == 0 ? 1.f : 0.f;
+#pragma unroll 4
         for (int j = 0; j < tile.t_cnt; ++j) {
             const int off = i - sP[j]; // n - P_t
             const bool in = off >= 0 && off < N;
-            const int oc = in ? off : 0;
             const int slot = (tile.t_first + j) & (a.FR - 1);
-            const float fv = fr[(int64_t)slot * N + oc];
-            const float wv = win[oc];
+            const float fv = fr[(int64_t)slot * N + (in ? off : 0)];
             acc += in ? fv : 0.f;
-            wacc += in ? wv * a.win_gain : 0.f;
         }
-        ola[i] = n >= 0 ? acc / wacc : 0.f;
+        ola[i] = tile.n_lo + i >= 0 ? acc / wacc[i] : 0.f;
     }
     __syncthreads();
 

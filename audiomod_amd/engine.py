@@ -90,6 +90,8 @@ def lib():
     L.pv_batch_out_frames.restype = C.c_int64
     L.pv_batch_slices.argtypes = [C.c_void_p]
     L.pv_batch_slices.restype = C.c_int64
+    L.pv_batch_launches.argtypes = [C.c_void_p]
+    L.pv_batch_launches.restype = C.c_int32
     L.pv_batch_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
     L.pv_batch_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pv_batch_enable_timing.argtypes = [C.c_void_p, C.c_int]
@@ -262,6 +264,7 @@ class Batch:
                                       C.byref(self.h)), "pv_batch_create")
         self.out_frames = self.L.pv_batch_out_frames(self.h)
         self.slices = self.L.pv_batch_slices(self.h)
+        self.launches = self.L.pv_batch_launches(self.h)
 
     def close(self):
         if getattr(self, "h", None):
@@ -295,8 +298,9 @@ class Batch:
                                    C.c_void_p(s.cuda_stream)), "pv_batch_run")
         return d_out
 
-    def enable_timing(self, on=True):
-        _check(self.L.pv_batch_enable_timing(self.h, 1 if on else 0), "pv_batch_enable_timing")
+    def enable_timing(self, every=1):
+        """every = 0/False: off; n: HIP events around the kernels of every n-th chunk."""
+        _check(self.L.pv_batch_enable_timing(self.h, int(every)), "pv_batch_enable_timing")
 
     def kernel_times(self):
         """{kernel: (total_ms, launches)} since enable_timing; synchronise the stream first."""

@@ -41,7 +41,7 @@ def make_input(torch, streams, frames, device, rank):
     return x
 
 
-def cpu_baseline(seconds=120):
+def cpu_baseline(seconds=480):
     """The real reference (oracle/_ref/ref_driver, kind 'reference') or, where absent, the oracle port,
     timed on ONE host core on one stereo stream of the same workload."""
     from audiomod_amd import signals
@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--seconds", type=int, default=20, help="audio seconds per stream per step")
     ap.add_argument("--coremode", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="split the streams into this many batches run concurrently on separate HIP streams")
+    ap.add_argument("--sample-every", type=int, default=8, help="instrument every n-th chunk with HIP events")
     args = ap.parse_args()
 
     import torch
@@ -95,12 +98,23 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     from audiomod_amd import engine as E
+    from audiomod_amd.sharding import max_over_ranks
     frames = args.seconds * 48000
     kw = dict(mode="normal_pitchshift", semitones=4.0, coremode=args.coremode, fftsize=2048)
-    batch = E.Batch(args.streams, frames, channels=2, block=480, flush=True, device=local_rank, **kw)
-    info = batch.info()
+    G = max(1, args.groups)
+    assert args.streams % G == 0, "--streams must be a multiple of --groups"
     d_in = make_input(torch, args.streams, frames, device, rank)
-    d_out = batch.alloc_out()
+    per = args.streams // G
+    batches = [E.Batch(per, frames, channels=2, block=480, flush=True, device=local_rank, **kw) for _ in range(G)]
+    ins = [d_in[g * per:(g + 1) * per] for g in range(G)]
+    outs = [b.alloc_out() for b in batches]
+    hip_streams = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device) for _ in range(G - 1)]
+    batch = batches[0]
+    info = batch.info()
+
+    def step():
+        for b, x, y, hs in zip(batches, ins, outs, hip_streams):
+            b.run(x, y, stream=hs)
 
     def barrier():
         torch.cuda.synchronize()
@@ -109,17 +123,18 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        batch.run(d_in, d_out)
+        step()
     barrier()
-    batch.enable_timing(True)
+    # HIP events around the kernels of every 8th chunk of group 0, inside the timed region (an event record
+    # costs stream time: instrumenting every launch slows the run by ~10 %, every 8th by ~1 %)
+    batch.enable_timing(args.sample_every)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        batch.run(d_in, d_out)
+        step()
     barrier()
     dt = time.perf_counter() - t0
     ktimes = batch.kernel_times()
-    batch.enable_timing(False)
-    from audiomod_amd.sharding import max_over_ranks
+    batch.enable_timing(0)
     dt = max_over_ranks(dt, dist, device)
 
     if rank == 0:
@@ -127,7 +142,8 @@ def main():
         ch_samples = total_streams * frames * 2 * args.steps
         value = ch_samples / dt / 1e6
         xrt_gpu = args.streams * args.seconds * args.steps / dt
-        slices_per_launch_total = batch.slices * 2 * args.streams  # per step, all chunks
+        slices_per_step_gpu = batch.slices * 2 * args.streams
+        slices_per_launch = batch.slices * 2 * per / batch.launches  # one launch = one chunk of one group
         N, H, s, h = info["fftsize"], info["fftsize"] // 2 + 1, info["hop_out_nominal"], info["hop_in"]
         # Algorithmic bytes per slice of each pipeline stage; they sum to SURVEY 8(d)'s
         # B_slice = 4*(3N+7H+2s+h).  The phase stage runs as two kernels (match + seq) in phase-locked
@@ -142,22 +158,23 @@ def main():
         per_kernel, per_stage = {}, {}
         for k, (ms, n) in ktimes.items():
             if n:
-                per_kernel[k] = {"avg_ms": round(ms / n, 4), "launches": int(n), "total_ms": round(ms, 2)}
+                per_kernel[k] = {"avg_ms": round(ms / n, 4), "samples": int(n)}
+        traffic_db = {}
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic_db = json.load(open(tpath)).get("bytes_per_launch", {})
         for name, (nbytes, ks) in stages.items():
             live = [k for k in ks if k in per_kernel]
             if not live:
                 continue
-            launches = per_kernel[live[0]]["launches"]
-            total_ms = sum(per_kernel[k]["total_ms"] for k in live)
-            slices_per_launch = slices_per_launch_total * args.steps / launches
-            avg_ms = total_ms / launches
-            per_stage[name] = {"kernels": live, "avg_ms": round(avg_ms, 4), "total_ms": round(total_ms, 2),
-                               "bytes_per_slice": nbytes, "slices_per_launch": round(slices_per_launch, 1),
+            avg_ms = sum(per_kernel[k]["avg_ms"] for k in live)
+            per_stage[name] = {"kernels": live, "avg_ms": round(avg_ms, 4), "bytes_per_slice": nbytes,
                                "GBps": round(nbytes * slices_per_launch / (avg_ms * 1e-3) / 1e9, 1)}
-        dom_stage = max(per_stage, key=lambda k: per_stage[k]["total_ms"])
-        dom = max(per_stage[dom_stage]["kernels"], key=lambda k: per_kernel[k]["total_ms"])
+        dom_stage = max(per_stage, key=lambda k: per_stage[k]["avg_ms"])
+        dom = max(per_stage[dom_stage]["kernels"], key=lambda k: per_kernel[k]["avg_ms"])
         achieved = per_stage[dom_stage]["GBps"]
-        pipeline_gbps = info["bytes_per_slice"] * slices_per_launch_total * args.steps / dt / 1e9
+        traffic = traffic_db.get(dom) if (G == 1 and args.streams == 128) else None
+        pipeline_gbps = info["bytes_per_slice"] * slices_per_step_gpu * args.steps / dt / 1e9
         line = {
             "metric": "Msamples/s (48 kHz stereo) phase-vocoder pitch-shift; x real-time per GPU",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -168,10 +185,12 @@ def main():
                                    if args.coremode == 1 else f"configs[1] with coremode {args.coremode}",
                        "streams_per_gpu": args.streams, "seconds_per_stream": args.seconds, "channels": 2,
                        "block": 480, "hop_in": h, "slices_per_channel": int(batch.slices),
+                       "concurrent_stream_groups": G, "launches_per_step": int(batch.launches) * G,
                        "parallelism": f"stream-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "stage": dom_stage, "pipeline_GBps": round(pipeline_gbps, 1), "per_stage": per_stage,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "stage": dom_stage, "slices_per_launch": round(slices_per_launch, 1),
+                         "pipeline_GBps": round(pipeline_gbps, 1), "per_stage": per_stage,
                          "per_kernel": per_kernel},
         }
         if world == 1 and not args.no_cpu_baseline:

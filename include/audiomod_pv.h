@@ -125,11 +125,14 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
 void pv_batch_destroy(pv_batch *b);
 int64_t pv_batch_out_frames(const pv_batch *b);
 int64_t pv_batch_slices(const pv_batch *b); /* slices per channel per stream */
+int32_t pv_batch_launches(const pv_batch *b); /* launches of each kernel per pv_batch_run (= chunks of slices) */
 int pv_batch_get_info(const pv_batch *b, pv_info *info);
 int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream);
 /* Optional per-kernel timing of the NEXT pv_batch_run calls (HIP events on the run's stream).
- * After synchronising the stream, pv_batch_kernel_times returns, for each of PV_NUM_KERNELS
- * kernels, the summed device time in ms and the launch count since timing was enabled. */
+ * pv_batch_enable_timing(b, n): n = 0 off; n >= 1 instruments every n-th chunk (n = 1: every launch; an event
+ * record costs stream time, so full instrumentation slows the run by about 10 %).  After synchronising the
+ * stream, pv_batch_kernel_times returns, for each of PV_NUM_KERNELS kernels, the summed device time in ms and
+ * the number of instrumented launches since timing was enabled, and resets the accumulation window. */
 #define PV_NUM_KERNELS 6
 #define PV_K_ANALYZE 0      /* window + forward real FFT + polar (+ peak picking) */
 #define PV_K_MATCH 1        /* phase-locked: peak matching, parallel part */
