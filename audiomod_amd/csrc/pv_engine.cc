@@ -7,6 +7,7 @@
 //
 // There is NO CPU fallback: without a gfx950 device every constructor returns PV_ERR_NO_DEVICE.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -605,6 +606,10 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
     int Tc = 16384 / (rows > 0 ? rows : 1);
     if (Tc < 16) Tc = 16;
     if (Tc > 256) Tc = 256;
+    if (const char *env = getenv("AUDIOMOD_PV_CHUNK_SLICES")) { // tuning knob: slices per launch and row
+        const int v = atoi(env);
+        if (v >= 4 && v <= 1024) Tc = v;
+    }
     int st = b->core.init(*cfg, device, nstreams, Tc);
     if (st != PV_OK) return st;
     Core &c = b->core;

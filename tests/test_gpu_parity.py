@@ -197,6 +197,50 @@ def test_full_size_single_stream_vs_oracle():
     assert rms(y, want) <= RMS_TOL
 
 
+@pytest.mark.parametrize("frames", [1, 100, 479, 2047, 2048, 2049, 5000])
+def test_short_inputs(frames):
+    """Inputs shorter than / around one FFT frame: the flush loop of the CLI drive pads with zeros."""
+    x = signals.voice(max(frames, 8), 2, seed=21)[:, :frames]
+    want, wc, _ = O.run_offline(x, semitones=4.0)
+    got, gc = E.run_offline(x, semitones=4.0)
+    assert gc == wc and got.shape == want.shape == (2, frames)
+    assert rms(got, want) <= RMS_TOL
+    import torch
+    bt = E.Batch(2, frames, channels=2, semitones=4.0)
+    out = bt.run(torch.from_numpy(np.stack([x, x])).cuda())
+    torch.cuda.synchronize()
+    assert bits_equal(out.cpu().numpy()[0], got)
+
+
+def test_many_channels_and_big_block():
+    x = signals.voice(30000, 6, seed=8)
+    want, wc, _ = O.run_offline(x, semitones=-4.0, block=7000)
+    got, gc = E.run_offline(x, semitones=-4.0, block=7000)
+    assert gc == wc
+    assert rms(got, want) <= RMS_TOL
+
+
+def test_coremode0_and_2_batch_full_chunking():
+    """coremode 0 (per-bin kernel) and 2 across several launches of the batch engine."""
+    import torch
+    x = signals.voice(6 * 48000, 2, seed=12)
+    for cm in (0, 2):
+        want, _, _ = O.run_offline(x, semitones=4.0, coremode=cm)
+        bt = E.Batch(1, x.shape[1], channels=2, semitones=4.0, coremode=cm)
+        out = bt.run(torch.from_numpy(x[None]).cuda())
+        torch.cuda.synchronize()
+        assert rms(out.cpu().numpy()[0], want) <= RMS_TOL
+
+
+def test_streaming_long_run_state_carry():
+    """Many small calls: per-row phase state is carried across hundreds of launches."""
+    x = signals.voice(4 * 48000, 2, seed=31)
+    want, wc, _ = O.run_offline(x, semitones=7.0, mode="gender_change", block=256)
+    got, gc = E.run_offline(x, semitones=7.0, mode="gender_change", block=256)
+    assert gc == wc
+    assert rms(got, want) <= RMS_TOL
+
+
 def test_unsupported_modes_fail_loudly():
     for mode in (E.CONSTANT, E.VOCODER_ROSENBERG, E.VOCODER_CHORD, E.WHISPER):
         with pytest.raises(E.PvError):
