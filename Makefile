@@ -31,4 +31,7 @@ clean:
 SHIM := audiomod_amd/lib/shim_demo
 $(SHIM): tools/shim_demo.cc $(LIB) include/dafx/phasevocoder.h include/dafx/modbase.h
 	$(HIPCC) -O2 -std=c++17 -Iinclude -Iinclude/dafx tools/shim_demo.cc -Laudiomod_amd/lib -laudiomod_pv -Wl,-rpath,'$$ORIGIN' -o $@
-all: $(SHIM)
+CLI := audiomod_amd/lib/audiomod-pv-exe
+$(CLI): audiomod_amd/csrc/audiomod_pv_cli.cc $(LIB) include/dafx/phasevocoder.h include/dafx/modbase.h
+	$(HIPCC) -O2 -std=c++17 -Iinclude -Iinclude/dafx audiomod_amd/csrc/audiomod_pv_cli.cc -Laudiomod_amd/lib -laudiomod_pv -Wl,-rpath,'$$ORIGIN' -o $@
+all: $(SHIM) $(CLI)

@@ -15,7 +15,7 @@ CXX := g++
 CC  := gcc
 CXXFLAGS := -O3 -DNDEBUG -std=gnu++14 -fPIC -w
 CFLAGS   := -O3 -DNDEBUG -fPIC -w
-INC := -I$(REF)/src -I$(REF)/include -I$(REF)/include/dafx
+INC := -I$(REF)/src -I$(REF)/include -I$(REF)/include/dafx -I$(REF)/include/analyzer
 
 # Only the files the phase-vocoder path needs (SURVEY.md section 2, rows 1-13 + 16).
 CXXSRC := $(wildcard $(REF)/src/phasevocoder/*.cc) \
@@ -27,7 +27,7 @@ CSRC   := $(wildcard $(REF)/src/common/kissfft/*.c) $(REF)/src/common/speex/resa
 CXXOBJ := $(patsubst $(REF)/%.cc,$(OUT)/obj/%.o,$(CXXSRC))
 COBJ   := $(patsubst $(REF)/%.c,$(OUT)/obj/%.o,$(CSRC))
 
-all: $(OUT)/ref_driver $(OUT)/ref_kat
+all: $(OUT)/ref_driver $(OUT)/ref_kat $(OUT)/audiomod-exe
 
 $(OUT)/obj/%.o: $(REF)/%.cc
 	@mkdir -p $(dir $@)
@@ -46,6 +46,13 @@ $(OUT)/ref_driver: oracle/ref_driver.cc $(OUT)/libaudiomod_ref.a
 
 $(OUT)/ref_kat: oracle/ref_kat.cc $(OUT)/libaudiomod_ref.a
 	$(CXX) $(CXXFLAGS) $(INC) $< $(OUT)/libaudiomod_ref.a -o $@ -static-libstdc++ -static-libgcc -lpthread -ldl
+
+# The reference's own CLI (used only to capture golden WAV files for the CLI/WAV counterpart).
+# main.cc instantiates every effect of the library, so this target compiles the whole reference tree.
+ALLCXX := $(wildcard $(REF)/src/*/*.cc) $(wildcard $(REF)/src/common/*/*.cc) $(wildcard $(REF)/main/*.cc)
+ALLOBJ := $(patsubst $(REF)/%.cc,$(OUT)/obj/%.o,$(ALLCXX))
+$(OUT)/audiomod-exe: $(ALLOBJ) $(COBJ)
+	$(CXX) $(CXXFLAGS) $(ALLOBJ) $(COBJ) -o $@ -static-libstdc++ -static-libgcc -lpthread -ldl
 
 clean:
 	rm -rf $(OUT)

@@ -71,6 +71,34 @@ def main():
                             meta=np.array(repr(meta)))
         print(f"e2e_{name}: in {x.shape} out {y.shape} calls {len(counts)}")
 
+    # ---- WAV goldens from the reference's own CLI: input WAV + the WAV audiomod-exe writes ----
+    import wave
+    exe = os.path.join(ROOT, "oracle", "_ref", "audiomod-exe")
+    wav_cases = [
+        ("normal_pitchshift", ["4", "1", "2048"], "voice2"),
+        ("time_stretch", ["1.5", "1", "4096"], "voice2"),
+        ("gender_change", ["-7", "1", "2048"], "voice1"),
+        ("robotic", [], "voice2"),
+    ]
+    with tempfile.TemporaryDirectory() as d:
+        for model, args, kind in wav_cases:
+            x = make_signal(kind)[:, :12000]
+            xi = np.round(x * 32768.0).astype("<i2")
+            fin, fout = os.path.join(d, "in.wav"), os.path.join(d, "out.wav")
+            with wave.open(fin, "wb") as w:
+                w.setnchannels(xi.shape[0])
+                w.setsampwidth(2)
+                w.setframerate(48000)
+                w.writeframes(np.ascontiguousarray(xi.T).tobytes())
+            subprocess.run([exe, model, fin, fout] + args, check=True, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL)
+            tag = model + ("_" + "_".join(args) if args else "")
+            np.savez_compressed(os.path.join(GOLD, f"wav_{tag}.npz"),
+                                in_wav=np.frombuffer(open(fin, "rb").read(), np.uint8),
+                                out_wav=np.frombuffer(open(fout, "rb").read(), np.uint8),
+                                argv=np.array(repr([model] + args)))
+            print(f"wav_{tag}: in {os.path.getsize(fin)} B out {os.path.getsize(fout)} B")
+
     # ---- unit KATs ----
     rng = np.random.default_rng(4242)
     kat = {}
