@@ -13,8 +13,10 @@
 namespace audiomod {
 
 static bool served_by_process_normal(int mode) {
+    // the engine runs CONSTANT through the same scheduling entry point (processConstant differs only in the
+    // per-slice work, reference phasevocoderimpl.cc:372-396)
     return mode == NORMAL_STRETCH || mode == NORMAL_SHIFT || mode == GENDER_CHANGE || mode == FORMANT_PRESERVE ||
-           mode == ROBOTIC;
+           mode == ROBOTIC || mode == WHISPER || mode == CONSTANT;
 }
 
 phasevocoder::phasevocoder(int sampleRate, int numChannels, float timeratio, float pitchshift, int mode,

@@ -122,8 +122,8 @@ struct Core {
     int build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64_t t_end, int64_t ka, int64_t kb,
                     int32_t p_index_base, std::vector<OlaTile> &tiles, std::vector<float> &wacc) const;
     void launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
-                      int ntiles, const int64_t *d_P, const float *d_wacc, float *out, int64_t out_stride_row,
-                      int64_t k_base,
+                      int ntiles, const int64_t *d_P, const float *d_wacc, const float *d_whisper, float *out,
+                      int64_t out_stride_row, int64_t k_base,
                       hipStream_t st, hipEvent_t *ev /* 2*PV_NUM_KERNELS events or null */) const;
 };
 
@@ -224,12 +224,13 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     if ((st = mag.alloc(planes * HP)) != PV_OK) return st;
     if ((st = phase.alloc(planes * HP)) != PV_OK) return st;
     if ((st = frames.alloc((size_t)rows * FR * d.N)) != PV_OK) return st;
-    if (!d.robotic && cm != 2) {
+    const bool bypass = d.robotic || d.whisper || d.constant; // modes without a phase recurrence
+    if (!bypass && cm != 2) {
         if ((st = outphase.alloc(planes * HP)) != PV_OK) return st;
         if ((st = st_po.alloc((size_t)rows * d.hs)) != PV_OK) return st;
         if ((st = st_pp.alloc((size_t)rows * d.hs)) != PV_OK) return st;
     }
-    if (!d.robotic && cm == 1) {
+    if (!bypass && cm == 1) {
         if ((st = peaks.alloc(planes * PKP)) != PV_OK) return st;
         if ((st = npk.alloc(planes)) != PV_OK) return st;
         if ((st = modes.alloc(planes)) != PV_OK) return st;
@@ -311,10 +312,11 @@ int Core::build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64
 }
 
 void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
-                        int ntiles, const int64_t *d_P, const float *d_wacc, float *out, int64_t out_stride_row,
-                        int64_t k_base,
+                        int ntiles, const int64_t *d_P, const float *d_wacc, const float *d_whisper, float *out,
+                        int64_t out_stride_row, int64_t k_base,
                         hipStream_t st, hipEvent_t *ev) const {
-    const int cm = d.robotic ? -1 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
+    const bool bypass = d.robotic || d.whisper || d.constant;
+    const int cm = bypass ? -1 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
     auto rec = [&](int i) {
         if (ev) (void)hipEventRecord(ev[i], st);
     };
@@ -421,6 +423,8 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     sa.fixed_gain = d.fixed_gain;
     sa.inv_n = d.inv_n;
     sa.robotic = d.robotic ? 1 : 0;
+    sa.passthru = d.constant ? 1 : 0;
+    sa.whisper = d.whisper ? d_whisper : nullptr;
     sa.coremode = cm < 0 ? 0 : cm;
     sa.t0 = t0;
     sa.s0 = s0;
@@ -518,6 +522,7 @@ struct pv_batch {
     DevBuf<int64_t> d_P;
     DevBuf<OlaTile> d_tiles;
     DevBuf<float> d_wacc;
+    DevBuf<float> d_whisper; // WHISPER mode: [slices][C][HP] host-drawn phases, shared by all streams
     int timing = 0; // 0 = off, n = instrument every n-th chunk
     std::vector<hipEvent_t> ev_pool; // kEvPerChunk per instrumented chunk
     std::vector<int> ev_chunk;       // chunk index of each used pool segment
@@ -537,7 +542,9 @@ struct pv_engine {
     int64_t fed = 0, uploaded = 0;
     hipStream_t stream = nullptr;
     int ring = 0; // device input ring length (power of two) per channel
-    DevBuf<float> d_in, d_out;
+    DevBuf<float> d_in, d_out, d_whisper;
+    PinBuf<float> h_whisper;
+    std::unique_ptr<WhisperRng> rng;
     DevBuf<char> d_desc;
     PinBuf<float> h_in, h_out;
     PinBuf<char> h_desc;
@@ -596,6 +603,13 @@ int pv_plan_simulate(const pv_config *cfg, const int32_t *n, int32_t ncalls, int
     return PV_OK;
 }
 
+int pv_plan_whisper_phases(int64_t n, float *out) {
+    if (n < 0 || (n > 0 && !out)) return PV_ERR_INVALID_ARG;
+    WhisperRng rng;
+    for (int64_t i = 0; i < n; ++i) out[i] = rng.next_phase();
+    return PV_OK;
+}
+
 // ---------------------------------------------------------------- batch
 int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int32_t block, int32_t flush, int device,
                     pv_batch **out) {
@@ -647,6 +661,16 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
     if ((st = b->d_P.upload(P)) != PV_OK) return st;
     if ((st = b->d_tiles.upload(tiles)) != PV_OK) return st;
     if ((st = b->d_wacc.upload(wacc)) != PV_OK) return st;
+    if (c.d.whisper) {
+        // every stream behaves like a fresh reference process, so all of them draw the same rand() sequence:
+        // slice-major, channel ch0, ch1, ..., bins 0..N/2 (whisperSlice runs inside processSliceForChannel)
+        WhisperRng rng;
+        std::vector<float> wp((size_t)T * c.C * c.HP, 0.f);
+        for (int64_t t = 0; t < T; ++t)
+            for (int ch = 0; ch < c.C; ++ch)
+                for (int k = 0; k <= c.d.hs; ++k) wp[((size_t)t * c.C + ch) * c.HP + k] = rng.next_phase();
+        if ((st = b->d_whisper.upload(wp)) != PV_OK) return st;
+    }
     *out = b.release();
     return PV_OK;
 }
@@ -705,7 +729,9 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
             b->ev_chunk.push_back((int)ci);
         }
         c.launch_chunk(ia, ch.t0, ch.Tn, b->d_pinc.p + ch.t0, b->d_tiles.p + ch.tile_begin, ch.ntiles, b->d_P.p,
-                       b->d_wacc.p + (size_t)ch.tile_begin * c.ola_lds_floats, d_out, b->plan.out_frames, 0, st, ev);
+                       b->d_wacc.p + (size_t)ch.tile_begin * c.ola_lds_floats,
+                       b->d_whisper.p ? b->d_whisper.p + (size_t)ch.t0 * c.C * c.HP : nullptr, d_out,
+                       b->plan.out_frames, 0, st, ev);
         ++ci;
     }
     HIPC(hipGetLastError());
@@ -716,7 +742,8 @@ int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launch
     if (!b) return PV_ERR_INVALID_ARG;
     // fold finished event pairs into the accumulators
     const Derived &d = b->core.d;
-    const int cm = d.robotic ? -1 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
+    const bool bypass = d.robotic || d.whisper || d.constant;
+    const int cm = bypass ? -1 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
     for (size_t i = 0; i + kEvPerChunk <= b->ev_used; i += kEvPerChunk) {
         const auto &ch = b->chunks[(size_t)b->ev_chunk[i / kEvPerChunk]];
         for (int k = 0; k < PV_NUM_KERNELS; ++k) {
@@ -764,6 +791,11 @@ int pv_create(const pv_config *cfg, int device, pv_engine **out) {
     const size_t desc_bytes = 256 * 1024;
     if ((st = e->d_desc.alloc(desc_bytes)) != PV_OK) return st;
     if ((st = e->h_desc.alloc(desc_bytes)) != PV_OK) return st;
+    if (c.d.whisper) {
+        e->rng.reset(new WhisperRng());
+        if ((st = e->d_whisper.alloc((size_t)kStreamChunk * c.C * c.HP)) != PV_OK) return st;
+        if ((st = e->h_whisper.alloc((size_t)kStreamChunk * c.C * c.HP)) != PV_OK) return st;
+    }
     e->outq.resize(c.C);
     *out = e.release();
     return PV_OK;
@@ -856,6 +888,14 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         }
         HIPC(hipMemcpyAsync(e->d_desc.p, hd, off, hipMemcpyHostToDevice, e->stream));
 
+        if (c.d.whisper) {
+            for (int i = 0; i < Tn; ++i)
+                for (int ch = 0; ch < c.C; ++ch)
+                    for (int k = 0; k <= c.d.hs; ++k)
+                        e->h_whisper.p[((size_t)i * c.C + ch) * c.HP + k] = e->rng->next_phase();
+            HIPC(hipMemcpyAsync(e->d_whisper.p, e->h_whisper.p, (size_t)Tn * c.C * c.HP * sizeof(float),
+                                hipMemcpyHostToDevice, e->stream));
+        }
         InAddr ia;
         ia.in = e->d_in.p;
         ia.stride_c = e->ring;
@@ -865,8 +905,8 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         c.launch_chunk(ia, ta, Tn, reinterpret_cast<const int32_t *>(e->d_desc.p),
                        reinterpret_cast<const OlaTile *>(e->d_desc.p + t_off_bytes), (int)tiles.size(),
                        reinterpret_cast<const int64_t *>(e->d_desc.p + p_off_bytes),
-                       reinterpret_cast<const float *>(e->d_desc.p + w_off_bytes), e->d_out.p, e->out_cap, ka,
-                       e->stream, nullptr);
+                       reinterpret_cast<const float *>(e->d_desc.p + w_off_bytes), e->d_whisper.p, e->d_out.p,
+                       e->out_cap, ka, e->stream, nullptr);
         (void)p_off_bytes;
         const int64_t cnt = kb - ka;
         if (cnt > 0) {

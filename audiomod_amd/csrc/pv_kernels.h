@@ -109,7 +109,9 @@ struct SynthArgs {
     double two_pi_hop;
     int do_freq_comp;
     float freq_comp, fixed_gain, inv_n;
-    int robotic;
+    int robotic;  // output phase = 0
+    int passthru; // CONSTANT mode: output phase = analysis phase
+    const float *whisper; // WHISPER mode: [Tn][C][HP] phases drawn on the host (else null)
     int coremode; // 0: phases from outphase; 1: per-step mode (rot / outphase); 2: phase * inc / hop
     int64_t t0;
     int s0;

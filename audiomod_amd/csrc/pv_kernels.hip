@@ -716,6 +716,11 @@ __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a
     // 1. output phase of every bin
     if (a.robotic) {
         for (int k = threadIdx.x; k <= hs; k += nt) sph[k] = 0.f;
+    } else if (a.passthru) {
+        for (int k = threadIdx.x; k <= hs; k += nt) sph[k] = A[k];
+    } else if (a.whisper) {
+        const float *__restrict__ wp = a.whisper + ((int64_t)tl * a.C + row % a.C) * tb.HP;
+        for (int k = threadIdx.x; k <= hs; k += nt) sph[k] = wp[k];
     } else if (a.coremode == 2) {
         const float pinc_f = (float)a.phase_inc[tl], hop_f = (float)a.hop;
         for (int k = threadIdx.x; k <= hs; k += nt) sph[k] = k < hs ? A[k] * pinc_f / hop_f : A[k];
@@ -830,6 +835,15 @@ template <int NC> __global__ __launch_bounds__(256) void pv_synth_wave_kernel(co
 #pragma unroll
         for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = 0.f;
         if (lane == 0) sph[hs] = 0.f;
+    } else if (a.passthru) {
+#pragma unroll
+        for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = A[lane + 64 * j];
+        if (lane == 0) sph[hs] = A[hs];
+    } else if (a.whisper) {
+        const float *__restrict__ wp = a.whisper + ((int64_t)tl * a.C + row % a.C) * tb.HP;
+#pragma unroll
+        for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = wp[lane + 64 * j];
+        if (lane == 0) sph[hs] = wp[hs];
     } else if (a.coremode == 2) {
         const float pinc_f = (float)a.phase_inc[tl], hop_f = (float)a.hop;
 #pragma unroll

@@ -202,14 +202,18 @@ int derive(const pv_config &cfg, Derived &d) {
     case PV_MODE_FORMANT_PRESERVE:
     case PV_MODE_NORMAL_STRETCH:
     case PV_MODE_ROBOTIC:
+    case PV_MODE_WHISPER:
+    case PV_MODE_CONSTANT:
         break;
     default:
-        return PV_ERR_UNSUPPORTED; // CONSTANT / VOCODER_* / WHISPER are outside the hot path
+        return PV_ERR_UNSUPPORTED; // the channel vocoder (VOCODER_*) is not built yet
     }
     // phasevocoder.cc:25-26: float semis/12, double pow, stored float
     d.time_ratio = cfg.time_ratio;
     d.pitch_scale = cfg.pitch_semitones != 0 ? (float)std::pow(2.0, cfg.pitch_semitones / 12) : 1.0f;
     d.robotic = cfg.mode == PV_MODE_ROBOTIC;
+    d.whisper = cfg.mode == PV_MODE_WHISPER;
+    d.constant = cfg.mode == PV_MODE_CONSTANT;
 
     size_t windowSize = next_pow2((size_t)cfg.fftsize);
     if (windowSize < 64 || windowSize > 16384) return PV_ERR_INVALID_ARG;
@@ -277,7 +281,7 @@ int derive(const pv_config &cfg, Derived &d) {
     if (st != PV_OK) return st;
 
     // smallest shift any slice can take: the clamp lrint(h*ratio/2) (phasevocoderprocess.cc:394-395)
-    if (d.robotic) d.min_shift = d.hop;
+    if (d.robotic || d.whisper || d.constant) d.min_shift = d.hop;
     else if (d.int_ratio) d.min_shift = (int)(size_t)(d.hop * hsr);
     else d.min_shift = (int)std::lrint(((size_t)d.hop * hsr) / 2);
     if (d.min_shift < 1) return PV_ERR_INVALID_ARG;
@@ -312,8 +316,8 @@ int Planner::try_slice(std::vector<SliceRec> &out) {
     if (in_fill_ < d_.N) return PV_OK; // inbufReady false -> processOneSlice returns early
     in_fill_ -= d_.hop;
     size_t phaseInc, shiftInc;
-    if (d_.robotic) {
-        phaseInc = shiftInc = (size_t)d_.hop;
+    if (d_.robotic || d_.whisper || d_.constant) {
+        phaseInc = shiftInc = (size_t)d_.hop; // :267-269 (robotic / whisper); processOneSliceConstant :139-150
     } else if (d_.int_ratio) {
         phaseInc = shiftInc = (size_t)((size_t)d_.hop * d_.hs_ratio);
     } else {
@@ -343,7 +347,7 @@ int Planner::try_slice(std::vector<SliceRec> &out) {
     }
     r.cnt = (int32_t)(Kn - K_);
     // output-ring guard (phasevocoderprocess.cc:337-364)
-    int required = int(shiftInc / d_.pitch_scale) + 1;
+    int required = d_.constant ? d_.hop : int(shiftInc / d_.pitch_scale) + 1; // :142 vs :337
     int64_t ws = d_.outbuf_cap - out_fill_;
     if (ws < required) return PV_ERR_OUTPUT_OVERRUN;
     out_fill_ += r.cnt;
@@ -397,6 +401,38 @@ int plan_batch(const Derived &d, int64_t frames, int block, bool flush, BatchPla
     bp.out_frames = produced;
     bp.in_frames = fed;
     return PV_OK;
+}
+
+// glibc rand(): TYPE_3 additive feedback generator x[i] = x[i-3] + x[i-31] (mod 2^32), output x >> 1, state
+// seeded from seed 1 by the Lehmer generator 16807 * s mod (2^31 - 1) and warmed up with 310 draws.  Written
+// from the published description of the algorithm; pinned against libc rand() in tests/test_host.py.
+WhisperRng::WhisperRng() {
+    int32_t r[34];
+    r[0] = 1;
+    for (int i = 1; i < 31; ++i) {
+        const int64_t hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+        int64_t w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        r[i] = (int32_t)w;
+    }
+    for (int i = 0; i < 31; ++i) state_[i] = r[i];
+    f_ = 3;
+    b_ = 0;
+    for (int i = 0; i < 310; ++i) (void)next_raw();
+}
+
+uint32_t WhisperRng::next_raw() {
+    const uint32_t v = (uint32_t)state_[f_] + (uint32_t)state_[b_];
+    state_[f_] = (int32_t)v;
+    const uint32_t out = v >> 1;
+    if (++f_ >= 31) f_ = 0;
+    if (++b_ >= 31) b_ = 0;
+    return out;
+}
+
+float WhisperRng::next_phase() {
+    const float two_pi = (float)(2 * M_PI);
+    return two_pi * (float)next_raw() / (float)2147483647; // RAND_MAX
 }
 
 int64_t bytes_per_slice(const Derived &d) {

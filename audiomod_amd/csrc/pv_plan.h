@@ -42,7 +42,9 @@ struct Derived {
     int outbuf_cap = 0; // output ring capacity (frames)
     float time_ratio = 1, pitch_scale = 1, hs_ratio = 1;
     bool int_ratio = false, resample = false;
-    bool robotic = false;
+    bool robotic = false;  // phase = 0 (roboticSlice)
+    bool whisper = false;  // phase = 2*pi*rand()/RAND_MAX (whisperSlice)
+    bool constant = false; // CONSTANT mode: no phase modification, out hop == in hop
     bool do_freq_comp = false;
     float freq_comp = 1, fixed_gain = 1;
     double two_pi_hop = 0; // (2*M_PI)*hop in double, the common factor of omega / pomega / delta_omega
@@ -106,5 +108,18 @@ struct BatchPlan {
 int plan_batch(const Derived &d, int64_t frames, int block, bool flush, BatchPlan &bp);
 
 int64_t bytes_per_slice(const Derived &d);
+
+// The phases whisperSlice (phasevocoderprocess.cc:814-822) draws in a fresh reference process: glibc's rand()
+// from its default seed, two_pi * (float)rand() / (float)RAND_MAX in float.
+class WhisperRng {
+  public:
+    WhisperRng();
+    float next_phase();
+    uint32_t next_raw();
+
+  private:
+    int32_t state_[31];
+    int f_, b_;
+};
 
 } // namespace pv

@@ -75,6 +75,7 @@ def lib():
     L.pv_kernel_name.argtypes = [C.c_int]
     L.pv_plan_simulate.argtypes = [C.POINTER(Config), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int64, C.POINTER(C.c_int64), C.POINTER(Info)]
+    L.pv_plan_whisper_phases.argtypes = [C.c_int64, C.c_void_p]
     L.pv_create.argtypes = [C.POINTER(Config), C.c_int, C.POINTER(C.c_void_p)]
     L.pv_destroy.argtypes = [C.c_void_p]
     L.pv_feed.argtypes = [C.c_void_p, fpp, C.c_int32]
@@ -127,6 +128,13 @@ def plan_simulate(calls, max_slices=1 << 22, **kw):
     _check(st, "pv_plan_simulate")
     k = min(ns.value, max_slices)
     return avail, shift[:k], phase[:k], info.as_dict()
+
+
+def whisper_phases(n):
+    """First n phases WHISPER mode draws in a fresh reference process (host only)."""
+    out = np.zeros(n, np.float32)
+    _check(lib().pv_plan_whisper_phases(n, out.ctypes.data), "pv_plan_whisper_phases")
+    return out
 
 
 def _pp(rows):
@@ -187,7 +195,7 @@ class PhaseVocoder:
         """In place on bufferData (float32 [channels, n]); check outputReady() afterwards."""
         assert bufferData.dtype == np.float32 and bufferData.flags.c_contiguous
         n = bufferData.shape[1]
-        if self.mode == NORMAL_STRETCH:  # the reference's processBlock ignores this mode
+        if self.mode == NORMAL_STRETCH:  # the reference's processBlock ignores this mode (phasevocoder.cc:134-144)
             self.outready_ = True
             return
         rows = [bufferData[c] for c in range(self.channels)]

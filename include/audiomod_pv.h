@@ -40,7 +40,7 @@ extern "C" {
 typedef enum pv_status {
     PV_OK = 0,
     PV_ERR_INVALID_ARG = 1,
-    PV_ERR_UNSUPPORTED = 2,   /* mode outside the hot path (vocoder/constant/whisper), or a resample ratio whose
+    PV_ERR_UNSUPPORTED = 2,   /* mode not built (the channel vocoder VOCODER_*), or a resample ratio whose
                                  per-slice output cap would bind (reference resampler.cc:783) */
     PV_ERR_NO_DEVICE = 3,     /* no usable MI355X / HIP runtime: the product has NO CPU fallback */
     PV_ERR_HIP = 4,           /* a HIP call failed; pv_last_error() has the text */
@@ -87,6 +87,9 @@ int pv_device_count(void);
  * -------------------------------------------------------------------------------------------- */
 int pv_plan_simulate(const pv_config *cfg, const int32_t *n, int32_t ncalls, int32_t *avail, int32_t *shift,
                      int32_t *phase, int64_t max_slices, int64_t *nslices, pv_info *info);
+/* The first n phases WHISPER mode assigns in a fresh reference process (glibc rand() from its default seed;
+ * reference phasevocoderprocess.cc:814-822), in draw order: slice-major, channel, bin 0..N/2. */
+int pv_plan_whisper_phases(int64_t n, float *out);
 
 /* ----------------------------------------------------------------------------------------------
  * Streaming engine: ONE stream of cfg->channels planar channels, host buffers in and out.

@@ -688,6 +688,9 @@ pvo *pvo_create(const pvo_config *cfg) {
         h->resamplebuf = (float *)xcalloc(rbs + 64, 4);
     }
     h->firstentry = 1;
+    /* whisperSlice draws from libc rand() (phasevocoderprocess.cc:820), never seeded by the reference: one
+     * oracle instance == one fresh process, so restart the default sequence */
+    if (h->opt_whisper) srand(1);
     h->peak = (int *)xcalloc(H, sizeof(int));
     h->prev_peak = (int *)xcalloc(H, sizeof(int));
     return h;
@@ -974,6 +977,34 @@ static int process_one_slice(pvo *h) {
     return outframes;
 }
 
+/* phasevocoderprocess.cc:122-156: CONSTANT mode -- no phase modification, in hop == out hop */
+static int process_one_slice_constant(pvo *h) {
+    const int C = h->cfg.channels;
+    const int N = (int)h->N;
+    for (int c = 0; c < C; ++c) {
+        chan *a = &h->ch[c];
+        if (ring_readspace(&a->inbuf) < N) return -1;
+        int ready = ring_readspace(&a->inbuf);
+        ring_peek(&a->inbuf, a->frame_t, ready < N ? ready : N);
+        ring_discard(&a->inbuf, (int)h->hop);
+        analyze(h, a);
+    }
+    record_incr(h, h->hop, h->hop);
+    int outframes = 0;
+    for (int c = 0; c < C; ++c) {
+        chan *a = &h->ch[c];
+        synthesise(h, a);
+        size_t ws = ring_writespace(&a->outbuf);
+        if (ws < h->hop) {
+            fprintf(stderr, "pv_oracle: Buffer overrun on output for channel %d\n", c);
+            return 0;
+        }
+        outframes = write_slice(h, a, h->hop);
+        a->slicecnt++;
+    }
+    return outframes;
+}
+
 int pvo_available(const pvo *h) {
     int ret = 0;
     for (int c = 0; c < h->cfg.channels; ++c) {
@@ -997,7 +1028,8 @@ int pvo_process(pvo *h, const float *const *in, int n) {
             nread[c] += towrite;
             allread = !(nread[c] < (size_t)n);
         }
-        process_one_slice(h);
+        if (h->cfg.mode == PVO_CONSTANT) process_one_slice_constant(h);
+        else process_one_slice(h);
     }
     free(nread);
     return pvo_available(h);

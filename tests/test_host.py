@@ -46,6 +46,9 @@ PLAN_CASES = [
     ([4800, 1, 0, 17, 20000, 480, 0, 0, 5], dict(channels=2, semitones=-3.0)),
     ([441] * 300, dict(channels=2, semitones=4.0, sample_rate=44100, fftsize=1024)),
     ([480] * 200, dict(channels=2, semitones=4.0, hopsize=128)),
+    ([480] * 100, dict(channels=2, mode="constant")),
+    ([480] * 100, dict(channels=2, mode="whisper")),
+    ([333] * 100, dict(channels=1, mode="constant", fftsize=1024)),
 ]
 
 
@@ -100,9 +103,21 @@ def test_errors():
     with pytest.raises(E.PvError):
         E.plan_simulate([480], channels=0, semitones=4.0)
     with pytest.raises(E.PvError):
-        E.plan_simulate([480], channels=2, mode="whisper")
+        E.plan_simulate([480], channels=2, mode="vocoder")
     with pytest.raises(E.PvError):  # output never retrieved: the reference's ring would overrun
         E.plan_simulate([100000], channels=2, semitones=-3.0)
+
+
+def test_whisper_phases_match_libc_rand():
+    """The engine's own glibc-compatible generator against the C library's rand() from its default seed."""
+    import ctypes.util
+    libc = ctypes.CDLL(ctypes.util.find_library("c"))
+    libc.srand(1)
+    n = 5000
+    raw = np.array([libc.rand() for _ in range(n)], dtype=np.float32)  # (float)rand()
+    want = (np.float32(2 * np.pi) * raw) / np.float32(2147483647)
+    got = E.whisper_phases(n)
+    assert np.array_equal(got.view(np.uint32), want.astype(np.float32).view(np.uint32))
 
 
 def test_fails_loudly_without_gpu():

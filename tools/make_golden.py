@@ -38,6 +38,8 @@ E2E = [
     ("shift+12_intratio", "voice2", dict(mode="normal_pitchshift", semitones=12.0, coremode=1, fftsize=2048)),
     ("sweep_shift-3_cm0", "sweep", dict(mode="normal_pitchshift", semitones=-3.0, coremode=0, fftsize=2048)),
     ("rt_shift+4_cm1", "voice2", dict(api="rt", mode="normal_pitchshift", semitones=4.0, coremode=1, fftsize=2048)),
+    ("constant_2048", "voice2", dict(mode="constant")),
+    ("whisper_2048", "voice2", dict(mode="whisper")),
 ]
 
 
