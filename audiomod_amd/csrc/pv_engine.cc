@@ -819,12 +819,12 @@ static int upload_until(pv_engine *e, const float *const *in, int64_t call_base,
         const int64_t roff = pos & (e->ring - 1);
         int64_t n = upto - pos;
         if (n > e->ring - roff) n = e->ring - roff;
-        for (int ch = 0; ch < c.C; ++ch) {
-            float *h = e->h_in.p + (size_t)ch * e->ring + roff;
-            memcpy(h, in[ch] + (pos - call_base), (size_t)n * sizeof(float));
-            HIPC(hipMemcpyAsync(e->d_in.p + (size_t)ch * e->ring + roff, h, (size_t)n * sizeof(float),
-                                hipMemcpyHostToDevice, e->stream));
-        }
+        for (int ch = 0; ch < c.C; ++ch)
+            memcpy(e->h_in.p + (size_t)ch * e->ring + roff, in[ch] + (pos - call_base), (size_t)n * sizeof(float));
+        // one strided copy for all channels (rows of n floats, pitch = ring)
+        HIPC(hipMemcpy2DAsync(e->d_in.p + roff, (size_t)e->ring * sizeof(float), e->h_in.p + roff,
+                              (size_t)e->ring * sizeof(float), (size_t)n * sizeof(float), (size_t)c.C,
+                              hipMemcpyHostToDevice, e->stream));
         e->uploaded += n;
     }
     return PV_OK;
@@ -909,11 +909,10 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
                        e->out_cap, ka, e->stream, nullptr);
         (void)p_off_bytes;
         const int64_t cnt = kb - ka;
-        if (cnt > 0) {
-            for (int ch = 0; ch < c.C; ++ch)
-                HIPC(hipMemcpyAsync(e->h_out.p + (size_t)ch * e->out_cap, e->d_out.p + (size_t)ch * e->out_cap,
-                                    (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-        }
+        if (cnt > 0)
+            HIPC(hipMemcpy2DAsync(e->h_out.p, (size_t)e->out_cap * sizeof(float), e->d_out.p,
+                                  (size_t)e->out_cap * sizeof(float), (size_t)cnt * sizeof(float), (size_t)c.C,
+                                  hipMemcpyDeviceToHost, e->stream));
         HIPC(hipStreamSynchronize(e->stream));
         HIPC(hipGetLastError());
         for (int ch = 0; ch < c.C && cnt > 0; ++ch) {

@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--seconds", type=int, default=20, help="audio seconds per stream per step")
     ap.add_argument("--coremode", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsals)")
+    ap.add_argument("--force-device", type=int, default=-1, help="use this device on every rank (rehearsals only)")
     ap.add_argument("--groups", type=int, default=1,
                     help="split the streams into this many batches run concurrently on separate HIP streams")
     ap.add_argument("--sample-every", type=int, default=8, help="instrument every n-th chunk with HIP events")
@@ -89,13 +91,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    if args.force_device >= 0:  # rehearsal of the N > 1 path on a one-GPU box (use with --dist-backend gloo)
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)  # RCCL: timing barrier + MAX reduce only
+        else:
+            dist.init_process_group(backend=args.dist_backend)
+    red_device = device if args.dist_backend == "nccl" else None
 
     from audiomod_amd import engine as E
     from audiomod_amd.sharding import max_over_ranks
@@ -135,7 +143,7 @@ def main():
     dt = time.perf_counter() - t0
     ktimes = batch.kernel_times()
     batch.enable_timing(0)
-    dt = max_over_ranks(dt, dist, device)
+    dt = max_over_ranks(dt, dist, red_device)
 
     if rank == 0:
         total_streams = args.streams * world
