@@ -109,6 +109,7 @@ struct Core {
     DevBuf<float> window, sinc;
     DevBuf<float4> tab4;
     DevBuf<float> mag, phase, outphase, frames, rot;
+    DevBuf<float> cmag, cphase; // vocoder: carrier planes [TR][HP]
     DevBuf<uint16_t> peaks;
     DevBuf<int32_t> npk, modes;
     DevBuf<PeakRec> recs;
@@ -122,8 +123,8 @@ struct Core {
     int build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64_t t_end, int64_t ka, int64_t kb,
                     int32_t p_index_base, std::vector<OlaTile> &tiles, std::vector<float> &wacc) const;
     void launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
-                      int ntiles, const int64_t *d_P, const float *d_wacc, const float *d_whisper, float *out,
-                      int64_t out_stride_row, int64_t k_base,
+                      int ntiles, const int64_t *d_P, const float *d_wacc, const float *d_whisper,
+                      const InAddr *carrier, float *out, int64_t out_stride_row, int64_t k_base,
                       hipStream_t st, hipEvent_t *ev /* 2*PV_NUM_KERNELS events or null */) const;
 };
 
@@ -224,7 +225,11 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     if ((st = mag.alloc(planes * HP)) != PV_OK) return st;
     if ((st = phase.alloc(planes * HP)) != PV_OK) return st;
     if ((st = frames.alloc((size_t)rows * FR * d.N)) != PV_OK) return st;
-    const bool bypass = d.robotic || d.whisper || d.constant; // modes without a phase recurrence
+    const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder; // modes without a phase recurrence
+    if (d.vocoder) {
+        if ((st = cmag.alloc((size_t)TR * HP)) != PV_OK) return st;
+        if ((st = cphase.alloc((size_t)TR * HP)) != PV_OK) return st;
+    }
     if (!bypass && cm != 2) {
         if ((st = outphase.alloc(planes * HP)) != PV_OK) return st;
         if ((st = st_po.alloc((size_t)rows * d.hs)) != PV_OK) return st;
@@ -312,10 +317,10 @@ int Core::build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64
 }
 
 void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
-                        int ntiles, const int64_t *d_P, const float *d_wacc, const float *d_whisper, float *out,
-                        int64_t out_stride_row, int64_t k_base,
+                        int ntiles, const int64_t *d_P, const float *d_wacc, const float *d_whisper,
+                        const InAddr *carrier, float *out, int64_t out_stride_row, int64_t k_base,
                         hipStream_t st, hipEvent_t *ev) const {
-    const bool bypass = d.robotic || d.whisper || d.constant;
+    const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder;
     const int cm = bypass ? -1 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
     auto rec = [&](int i) {
         if (ev) (void)hipEventRecord(ev[i], st);
@@ -338,6 +343,16 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     aa.npk = npk.p;
     rec(2 * PV_K_ANALYZE);
     launch_analyze(aa, st);
+    if (d.vocoder && carrier) {
+        // the carrier is one more (data-independent) row: same analysis, its own planes
+        AnalyzeArgs ca = aa;
+        ca.ia = *carrier;
+        ca.rows = 1;
+        ca.find_peaks = 0;
+        ca.mag = cmag.p;
+        ca.phase = cphase.p;
+        launch_analyze(ca, st);
+    }
     rec(2 * PV_K_ANALYZE + 1);
 
     if (cm == 1) {
@@ -425,6 +440,9 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     sa.robotic = d.robotic ? 1 : 0;
     sa.passthru = d.constant ? 1 : 0;
     sa.whisper = d.whisper ? d_whisper : nullptr;
+    sa.voc_band_len = d.vocoder ? d.voc_band_len : -1;
+    sa.cmag = cmag.p;
+    sa.cphase = cphase.p;
     sa.coremode = cm < 0 ? 0 : cm;
     sa.t0 = t0;
     sa.s0 = s0;
@@ -523,6 +541,7 @@ struct pv_batch {
     DevBuf<OlaTile> d_tiles;
     DevBuf<float> d_wacc;
     DevBuf<float> d_whisper; // WHISPER mode: [slices][C][HP] host-drawn phases, shared by all streams
+    DevBuf<float> d_carrier; // vocoder modes: the carrier signal for every sample fed (incl. the zero flush)
     int timing = 0; // 0 = off, n = instrument every n-th chunk
     std::vector<hipEvent_t> ev_pool; // kEvPerChunk per instrumented chunk
     std::vector<int> ev_chunk;       // chunk index of each used pool segment
@@ -542,9 +561,10 @@ struct pv_engine {
     int64_t fed = 0, uploaded = 0;
     hipStream_t stream = nullptr;
     int ring = 0; // device input ring length (power of two) per channel
-    DevBuf<float> d_in, d_out, d_whisper;
-    PinBuf<float> h_whisper;
+    DevBuf<float> d_in, d_out, d_whisper, d_carrier;
+    PinBuf<float> h_whisper, h_carrier;
     std::unique_ptr<WhisperRng> rng;
+    std::unique_ptr<CarrierGen> cargen;
     DevBuf<char> d_desc;
     PinBuf<float> h_in, h_out;
     PinBuf<char> h_desc;
@@ -661,6 +681,12 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
     if ((st = b->d_P.upload(P)) != PV_OK) return st;
     if ((st = b->d_tiles.upload(tiles)) != PV_OK) return st;
     if ((st = b->d_wacc.upload(wacc)) != PV_OK) return st;
+    if (c.d.vocoder) {
+        CarrierGen gen((float)c.d.cfg.sample_rate, c.d.chord);
+        std::vector<float> car((size_t)b->plan.in_frames);
+        for (auto &v : car) v = gen.next();
+        if ((st = b->d_carrier.upload(car)) != PV_OK) return st;
+    }
     if (c.d.whisper) {
         // every stream behaves like a fresh reference process, so all of them draw the same rand() sequence:
         // slice-major, channel ch0, ch1, ..., bins 0..N/2 (whisperSlice runs inside processSliceForChannel)
@@ -714,6 +740,12 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
     ia.len = b->frames;
     // Instrumentation: HIP events around each kernel of every `timing`-th chunk.  An event record costs a few
     // microseconds of stream time, so instrumenting every launch would slow the run it measures by ~10 %.
+    InAddr car{};
+    car.in = b->d_carrier.p;
+    car.stride_c = 0;
+    car.stride_s = 0;
+    car.mask = ~0ull;
+    car.len = (int64_t)b->d_carrier.n;
     size_t ci = 0;
     for (const auto &ch : b->chunks) {
         hipEvent_t *ev = nullptr;
@@ -730,8 +762,8 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
         }
         c.launch_chunk(ia, ch.t0, ch.Tn, b->d_pinc.p + ch.t0, b->d_tiles.p + ch.tile_begin, ch.ntiles, b->d_P.p,
                        b->d_wacc.p + (size_t)ch.tile_begin * c.ola_lds_floats,
-                       b->d_whisper.p ? b->d_whisper.p + (size_t)ch.t0 * c.C * c.HP : nullptr, d_out,
-                       b->plan.out_frames, 0, st, ev);
+                       b->d_whisper.p ? b->d_whisper.p + (size_t)ch.t0 * c.C * c.HP : nullptr,
+                       c.d.vocoder ? &car : nullptr, d_out, b->plan.out_frames, 0, st, ev);
         ++ci;
     }
     HIPC(hipGetLastError());
@@ -742,7 +774,7 @@ int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launch
     if (!b) return PV_ERR_INVALID_ARG;
     // fold finished event pairs into the accumulators
     const Derived &d = b->core.d;
-    const bool bypass = d.robotic || d.whisper || d.constant;
+    const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder;
     const int cm = bypass ? -1 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
     for (size_t i = 0; i + kEvPerChunk <= b->ev_used; i += kEvPerChunk) {
         const auto &ch = b->chunks[(size_t)b->ev_chunk[i / kEvPerChunk]];
@@ -791,6 +823,12 @@ int pv_create(const pv_config *cfg, int device, pv_engine **out) {
     const size_t desc_bytes = 256 * 1024;
     if ((st = e->d_desc.alloc(desc_bytes)) != PV_OK) return st;
     if ((st = e->h_desc.alloc(desc_bytes)) != PV_OK) return st;
+    if (c.d.vocoder) {
+        e->cargen.reset(new CarrierGen((float)cfg->sample_rate, c.d.chord));
+        if ((st = e->d_carrier.alloc((size_t)e->ring)) != PV_OK) return st;
+        HIPC(hipMemset(e->d_carrier.p, 0, (size_t)e->ring * sizeof(float)));
+        if ((st = e->h_carrier.alloc((size_t)e->ring)) != PV_OK) return st;
+    }
     if (c.d.whisper) {
         e->rng.reset(new WhisperRng());
         if ((st = e->d_whisper.alloc((size_t)kStreamChunk * c.C * c.HP)) != PV_OK) return st;
@@ -821,6 +859,11 @@ static int upload_until(pv_engine *e, const float *const *in, int64_t call_base,
         if (n > e->ring - roff) n = e->ring - roff;
         for (int ch = 0; ch < c.C; ++ch)
             memcpy(e->h_in.p + (size_t)ch * e->ring + roff, in[ch] + (pos - call_base), (size_t)n * sizeof(float));
+        if (e->cargen) { // the carrier advances in lock-step with the input samples
+            float *hc = e->h_carrier.p + roff;
+            for (int64_t i = 0; i < n; ++i) hc[i] = e->cargen->next();
+            HIPC(hipMemcpyAsync(e->d_carrier.p + roff, hc, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        }
         // one strided copy for all channels (rows of n floats, pitch = ring)
         HIPC(hipMemcpy2DAsync(e->d_in.p + roff, (size_t)e->ring * sizeof(float), e->h_in.p + roff,
                               (size_t)e->ring * sizeof(float), (size_t)n * sizeof(float), (size_t)c.C,
@@ -902,11 +945,15 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         ia.stride_s = (int64_t)e->ring * c.C;
         ia.mask = (uint64_t)(e->ring - 1);
         ia.len = INT64_MAX;
+        InAddr car = ia;
+        car.in = e->d_carrier.p;
+        car.stride_c = 0;
+        car.stride_s = 0;
         c.launch_chunk(ia, ta, Tn, reinterpret_cast<const int32_t *>(e->d_desc.p),
                        reinterpret_cast<const OlaTile *>(e->d_desc.p + t_off_bytes), (int)tiles.size(),
                        reinterpret_cast<const int64_t *>(e->d_desc.p + p_off_bytes),
-                       reinterpret_cast<const float *>(e->d_desc.p + w_off_bytes), e->d_whisper.p, e->d_out.p,
-                       e->out_cap, ka, e->stream, nullptr);
+                       reinterpret_cast<const float *>(e->d_desc.p + w_off_bytes), e->d_whisper.p,
+                       c.d.vocoder ? &car : nullptr, e->d_out.p, e->out_cap, ka, e->stream, nullptr);
         (void)p_off_bytes;
         const int64_t cnt = kb - ka;
         if (cnt > 0)

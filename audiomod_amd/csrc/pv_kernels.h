@@ -112,6 +112,10 @@ struct SynthArgs {
     int robotic;  // output phase = 0
     int passthru; // CONSTANT mode: output phase = analysis phase
     const float *whisper; // WHISPER mode: [Tn][C][HP] phases drawn on the host (else null)
+    // channel vocoder: carrier planes [TR][HP] (one row, shared by every stream and channel); band_len < 0 = off
+    int voc_band_len;
+    const float *cmag;
+    const float *cphase;
     int coremode; // 0: phases from outphase; 1: per-step mode (rot / outphase); 2: phase * inc / hop
     int64_t t0;
     int s0;

@@ -696,6 +696,22 @@ void launch_prop(const PropArgs &a, hipStream_t st) {
 // --------------------------------------------------------------------------------------------
 // synthesis (+ per-bin application of the phase modification)
 // --------------------------------------------------------------------------------------------
+// modifySliceVocoder (phasevocoderprocess.cc:755-776): carrier magnitude of bin k times the mean modulator
+// magnitude of its band (band_len bins, float running sum from 0, divided by band_len*2); DC and Nyquist zeroed.
+__device__ __forceinline__ float vocoder_mag(const float *__restrict__ mod, const float *__restrict__ cmag, int k,
+                                             int hs, int band_len) {
+    if (k == 0 || k == hs) return 0.f;
+    float mg = cmag[k];
+    if (band_len > 0 && k < 512 * band_len) {
+        const int j0 = (k / band_len) * band_len;
+        float mean = 0.f;
+        for (int i = 0; i < band_len; ++i) mean += mod[j0 + i];
+        mean /= (float)(band_len * 2);
+        mg *= mean;
+    }
+    return mg;
+}
+
 __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const DevTables &tb = a.tb;
@@ -714,7 +730,11 @@ __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a
     const double Nd = (double)N;
 
     // 1. output phase of every bin
-    if (a.robotic) {
+    const int cslot = ring_slot(a.s0, tl, a.TR);
+    if (a.voc_band_len >= 0) {
+        const float *__restrict__ cp = a.cphase + (int64_t)cslot * tb.HP;
+        for (int k = threadIdx.x; k <= hs; k += nt) sph[k] = cp[k];
+    } else if (a.robotic) {
         for (int k = threadIdx.x; k <= hs; k += nt) sph[k] = 0.f;
     } else if (a.passthru) {
         for (int k = threadIdx.x; k <= hs; k += nt) sph[k] = A[k];
@@ -767,6 +787,9 @@ __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a
                 p = sph[k];
             }
             mg *= a.fixed_gain;
+        } else if (a.voc_band_len >= 0) {
+            mg = vocoder_mag(mag, a.cmag + (int64_t)cslot * tb.HP, k, hs, a.voc_band_len);
+            p = sph[k];
         } else {
             mg = mag[k];
             p = sph[k];
@@ -831,7 +854,13 @@ template <int NC> __global__ __launch_bounds__(256) void pv_synth_wave_kernel(co
     constexpr int JB = NC / 64; // bins per lane (plus the Nyquist bin on lane 0)
 
     // 1. output phase of every bin -> sph
-    if (a.robotic) {
+    const int cslot = ring_slot(a.s0, tl, a.TR);
+    if (a.voc_band_len >= 0) {
+        const float *__restrict__ cp = a.cphase + (int64_t)cslot * tb.HP;
+#pragma unroll
+        for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = cp[lane + 64 * j];
+        if (lane == 0) sph[hs] = cp[hs];
+    } else if (a.robotic) {
 #pragma unroll
         for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = 0.f;
         if (lane == 0) sph[hs] = 0.f;
@@ -915,6 +944,9 @@ template <int NC> __global__ __launch_bounds__(256) void pv_synth_wave_kernel(co
                 p = sph[k];
             }
             mg *= a.fixed_gain;
+        } else if (a.voc_band_len >= 0) {
+            mg = vocoder_mag(mag, a.cmag + (int64_t)cslot * tb.HP, k, hs, a.voc_band_len);
+            p = sph[k];
         } else {
             mg = mag[k];
             p = sph[k];

@@ -204,9 +204,11 @@ int derive(const pv_config &cfg, Derived &d) {
     case PV_MODE_ROBOTIC:
     case PV_MODE_WHISPER:
     case PV_MODE_CONSTANT:
+    case PV_MODE_VOCODER_ROSENBERG:
+    case PV_MODE_VOCODER_CHORD:
         break;
     default:
-        return PV_ERR_UNSUPPORTED; // the channel vocoder (VOCODER_*) is not built yet
+        return PV_ERR_UNSUPPORTED;
     }
     // phasevocoder.cc:25-26: float semis/12, double pow, stored float
     d.time_ratio = cfg.time_ratio;
@@ -214,6 +216,8 @@ int derive(const pv_config &cfg, Derived &d) {
     d.robotic = cfg.mode == PV_MODE_ROBOTIC;
     d.whisper = cfg.mode == PV_MODE_WHISPER;
     d.constant = cfg.mode == PV_MODE_CONSTANT;
+    d.vocoder = cfg.mode == PV_MODE_VOCODER_ROSENBERG || cfg.mode == PV_MODE_VOCODER_CHORD;
+    d.chord = cfg.mode == PV_MODE_VOCODER_CHORD;
 
     size_t windowSize = next_pow2((size_t)cfg.fftsize);
     if (windowSize < 64 || windowSize > 16384) return PV_ERR_INVALID_ARG;
@@ -255,7 +259,8 @@ int derive(const pv_config &cfg, Derived &d) {
         float efr = hsr;
         d.int_ratio = std::fabs(efr - std::floor(efr)) <= 0.001; // float abs overload in the reference build
     }
-    d.resample = d.pitch_scale != 1.0;
+    d.resample = d.pitch_scale != 1.0 && !d.vocoder; // writeSliceCarrier never resamples (:1196-1231)
+    d.voc_band_len = (int)std::floor(float(windowSize) / float(512 * 2));
     d.two_pi_hop = 2 * M_PI * (size_t)d.hop;
     d.inv_n = 1.f / (size_t)d.N;
 
@@ -281,7 +286,7 @@ int derive(const pv_config &cfg, Derived &d) {
     if (st != PV_OK) return st;
 
     // smallest shift any slice can take: the clamp lrint(h*ratio/2) (phasevocoderprocess.cc:394-395)
-    if (d.robotic || d.whisper || d.constant) d.min_shift = d.hop;
+    if (d.robotic || d.whisper || d.constant || d.vocoder) d.min_shift = d.hop;
     else if (d.int_ratio) d.min_shift = (int)(size_t)(d.hop * hsr);
     else d.min_shift = (int)std::lrint(((size_t)d.hop * hsr) / 2);
     if (d.min_shift < 1) return PV_ERR_INVALID_ARG;
@@ -316,7 +321,7 @@ int Planner::try_slice(std::vector<SliceRec> &out) {
     if (in_fill_ < d_.N) return PV_OK; // inbufReady false -> processOneSlice returns early
     in_fill_ -= d_.hop;
     size_t phaseInc, shiftInc;
-    if (d_.robotic || d_.whisper || d_.constant) {
+    if (d_.robotic || d_.whisper || d_.constant || d_.vocoder) {
         phaseInc = shiftInc = (size_t)d_.hop; // :267-269 (robotic / whisper); processOneSliceConstant :139-150
     } else if (d_.int_ratio) {
         phaseInc = shiftInc = (size_t)((size_t)d_.hop * d_.hs_ratio);
@@ -347,7 +352,7 @@ int Planner::try_slice(std::vector<SliceRec> &out) {
     }
     r.cnt = (int32_t)(Kn - K_);
     // output-ring guard (phasevocoderprocess.cc:337-364)
-    int required = d_.constant ? d_.hop : int(shiftInc / d_.pitch_scale) + 1; // :142 vs :337
+    int required = (d_.constant || d_.vocoder) ? d_.hop : int(shiftInc / d_.pitch_scale) + 1; // :142, :1203 vs :337
     int64_t ws = d_.outbuf_cap - out_fill_;
     if (ws < required) return PV_ERR_OUTPUT_OVERRUN;
     out_fill_ += r.cnt;
@@ -401,6 +406,47 @@ int plan_batch(const Derived &d, int64_t frames, int block, bool flush, BatchPla
     bp.out_frames = produced;
     bp.in_frames = fed;
     return PV_OK;
+}
+
+void CarrierGen::init(Voice &v, float sample_rate, float freq, float alpha, float beta) {
+    v.period = (int)std::round(1.f / freq * sample_rate);
+    v.phase = 0;
+    v.n1 = (int)std::round(alpha * v.period);
+    v.inv_n1 = 1.f / static_cast<float>(v.n1);
+    v.n2 = (int)std::round(beta * v.period);
+    v.inv_2n2 = (float)(0.5 / static_cast<float>(v.n2));
+}
+
+float CarrierGen::step(Voice &v) {
+    float res = 0;
+    if (v.phase <= v.n1) {
+        res = (float)(0.5 * (1 - cosf((float)(M_PI * v.phase * v.inv_n1))));
+    } else if (v.phase - v.n1 <= v.n2) {
+        res = cosf((float)(M_PI * (v.phase - v.n1) * v.inv_2n2));
+    } else {
+        res = 0;
+    }
+    if (++v.phase > v.period) v.phase = 0;
+    return res;
+}
+
+CarrierGen::CarrierGen(float sample_rate, bool chord) {
+    const float alpha = 0.01f, beta = 0.06f;
+    if (chord) {
+        const float f[3] = {440, 523.251f, 659.255f};
+        nv_ = 3;
+        for (int i = 0; i < 3; ++i) init(v_[i], sample_rate, f[i], alpha, beta);
+    } else {
+        nv_ = 1;
+        init(v_[0], sample_rate, 440, alpha, beta);
+    }
+}
+
+float CarrierGen::next() {
+    if (nv_ == 1) return (float)(step(v_[0]) * 0.3);
+    float res = 0;
+    for (int i = 0; i < 3; ++i) res += step(v_[i]) / 3;
+    return (float)(res * 0.3);
 }
 
 // glibc rand(): TYPE_3 additive feedback generator x[i] = x[i-3] + x[i-31] (mod 2^32), output x >> 1, state

@@ -45,6 +45,9 @@ struct Derived {
     bool robotic = false;  // phase = 0 (roboticSlice)
     bool whisper = false;  // phase = 2*pi*rand()/RAND_MAX (whisperSlice)
     bool constant = false; // CONSTANT mode: no phase modification, out hop == in hop
+    bool vocoder = false;  // channel vocoder: Rosenberg carrier shaped by the input's band magnitudes
+    bool chord = false;    // VOCODER_CHORD: three-voice A-minor carrier
+    int voc_band_len = 0;  // bins per band = floor(N / 1024) (modifySliceVocoder)
     bool do_freq_comp = false;
     float freq_comp = 1, fixed_gain = 1;
     double two_pi_hop = 0; // (2*M_PI)*hop in double, the common factor of omega / pomega / delta_omega
@@ -111,6 +114,25 @@ int64_t bytes_per_slice(const Derived &d);
 
 // The phases whisperSlice (phasevocoderprocess.cc:814-822) draws in a fresh reference process: glibc's rand()
 // from its default seed, two_pi * (float)rand() / (float)RAND_MAX in float.
+// The carrier of the vocoder modes: Rosenberg glottal pulse train at 440 Hz, or the A-minor chord
+// {440, 523.251, 659.255} Hz, scaled by 0.3 (reference common/gen/rosenberg.cc:19-53, rosenbergchord.cc:19-43,
+// phasevocoderimpl.cc:312-320, phasevocoderprocess.cc:96-107).  Data-independent and identical for every channel.
+class CarrierGen {
+  public:
+    CarrierGen(float sample_rate, bool chord);
+    float next();
+
+  private:
+    struct Voice {
+        int period, n1, n2, phase;
+        float inv_n1, inv_2n2;
+    };
+    static void init(Voice &v, float sample_rate, float freq, float alpha, float beta);
+    static float step(Voice &v);
+    Voice v_[3];
+    int nv_;
+};
+
 class WhisperRng {
   public:
     WhisperRng();

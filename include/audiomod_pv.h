@@ -40,7 +40,7 @@ extern "C" {
 typedef enum pv_status {
     PV_OK = 0,
     PV_ERR_INVALID_ARG = 1,
-    PV_ERR_UNSUPPORTED = 2,   /* mode not built (the channel vocoder VOCODER_*), or a resample ratio whose
+    PV_ERR_UNSUPPORTED = 2,   /* unknown mode, fftsize above 8192, or a resample ratio whose
                                  per-slice output cap would bind (reference resampler.cc:783) */
     PV_ERR_NO_DEVICE = 3,     /* no usable MI355X / HIP runtime: the product has NO CPU fallback */
     PV_ERR_HIP = 4,           /* a HIP call failed; pv_last_error() has the text */

@@ -31,8 +31,7 @@ namespace audiomod {
 class phasevocoder : public modbase, public modbase_offline {
   public:
     // timeratio: output length / input length; pitchshift: semitones; hopsize 0 = automatic.
-    // Throws std::runtime_error when no MI355X is usable or the mode is outside the GPU hot path
-    // (the channel vocoder modes VOCODER_*): there is no CPU fallback.
+    // Throws std::runtime_error when no MI355X is usable (there is no CPU fallback) or the arguments are invalid.
     phasevocoder(int sampleRate, int numChannels, float timeratio, float pitchshift, int mode = NORMAL_SHIFT,
                  int coremode = PHASE_LOCKED, int fftsize = 2048, int hopsize = 0);
     ~phasevocoder();

@@ -585,8 +585,40 @@ typedef struct {
     long slicecnt;
 } chan;
 
+/* Rosenberg glottal-pulse carrier (src/common/gen/rosenberg.cc:19-53) and the 3-voice chord
+ * (src/common/gen/rosenbergchord.cc:19-43) */
+typedef struct {
+    int period, n1, n2, phase;
+    float inv_n1, inv_2n2;
+} rsb;
+
+static void rsb_init(rsb *g, float sample_rate, float freq, float alpha, float beta) {
+    g->period = round(1.f / freq * sample_rate);
+    g->phase = 0;
+    g->n1 = round(alpha * g->period);
+    g->inv_n1 = 1.f / (float)(g->n1);
+    g->n2 = round(beta * g->period);
+    g->inv_2n2 = 0.5 / (float)(g->n2);
+}
+
+static float rsb_next(rsb *g) {
+    float res = 0;
+    if (g->phase <= g->n1) {
+        res = 0.5 * (1 - cosf(M_PI * g->phase * g->inv_n1));
+    } else if (g->phase - g->n1 <= g->n2) {
+        res = cosf(M_PI * (g->phase - g->n1) * g->inv_2n2);
+    } else {
+        res = 0;
+    }
+    if (++g->phase > g->period) g->phase = 0;
+    return res;
+}
+
 struct pvo {
     pvo_config cfg;
+    chan *car;        /* carrier channelinfo per channel (vocoder modes) */
+    rsb *gen;         /* [channels] single-voice generators */
+    rsb *chord;       /* [channels][3] */
     int opt_gender, opt_formant, opt_robotic, opt_whisper;
     float time_ratio, pitch_scale;
     size_t N, hop, outbuf_size;
@@ -681,6 +713,28 @@ pvo *pvo_create(const pvo_config *cfg) {
         a->res = pvo_res_create();
         a->wacc[0] = 1.f; /* channelinfo.cc:108 */
     }
+    h->car = (chan *)xcalloc(C, sizeof(chan));
+    h->gen = (rsb *)xcalloc(C, sizeof(rsb));
+    h->chord = (rsb *)xcalloc(3 * C, sizeof(rsb));
+    for (int c = 0; c < C; ++c) {
+        chan *a = &h->car[c];
+        size_t bufferSize = 2 * N;
+        size_t ob = h->outbuf_size < bufferSize ? bufferSize : h->outbuf_size;
+        ring_init(&a->inbuf, (int)bufferSize);
+        ring_init(&a->outbuf, (int)ob);
+        a->mag = (float *)xcalloc(H, 4); a->phase = (float *)xcalloc(H, 4);
+        a->prev_phase = (float *)xcalloc(H, 4); a->prev_outphase = (float *)xcalloc(H, 4);
+        a->locked_phase = (float *)xcalloc(H, 4);
+        a->oacc = (float *)xcalloc(bufferSize, 4); a->wacc = (float *)xcalloc(bufferSize, 4);
+        a->frame_t = (float *)xcalloc(bufferSize, 4); a->frame_f = (float *)xcalloc(bufferSize, 4);
+        a->fft = rfft_new((int)N);
+        a->res = pvo_res_create();
+        a->wacc[0] = 1.f;
+        /* phasevocoderimpl.cc:312-320: 440 Hz pulse; A-minor chord on A4 */
+        rsb_init(&h->gen[c], (float)cfg->sample_rate, 440, 0.01, 0.06);
+        const float chordmin[3] = {440, 523.251, 659.255};
+        for (int v = 0; v < 3; ++v) rsb_init(&h->chord[3 * c + v], (float)cfg->sample_rate, chordmin[v], 0.01, 0.06);
+    }
     {
         size_t rbs = lrintf(ceil((h->hop * h->time_ratio * 2) / h->pitch_scale));
         if (rbs < h->hop * 16) rbs = h->hop * 16;
@@ -706,6 +760,15 @@ void pvo_destroy(pvo *h) {
         rfft_free(a->fft);
         pvo_res_destroy(a->res);
     }
+    for (int c = 0; c < h->cfg.channels; ++c) {
+        chan *a = &h->car[c];
+        ring_free(&a->inbuf); ring_free(&a->outbuf);
+        free(a->mag); free(a->phase); free(a->prev_phase); free(a->prev_outphase); free(a->locked_phase);
+        free(a->oacc); free(a->wacc); free(a->frame_t); free(a->frame_f);
+        rfft_free(a->fft);
+        pvo_res_destroy(a->res);
+    }
+    free(h->car); free(h->gen); free(h->chord);
     free(h->ch); free(h->win); free(h->peak); free(h->prev_peak); free(h->resamplebuf);
     free(h->rec_shift); free(h->rec_phase);
     free(h);
@@ -1005,10 +1068,77 @@ static int process_one_slice_constant(pvo *h) {
     return outframes;
 }
 
+static int is_vocoder(const pvo *h) {
+    return h->cfg.mode == PVO_VOCODER_ROSENBERG || h->cfg.mode == PVO_VOCODER_CHORD;
+}
+
+/* phasevocoderprocess.cc:158-195 processOneSliceVocoder, :755-776 modifySliceVocoder,
+ * :1077-1107 synthesiseSliceCarrier, :1196-1231 writeSliceCarrier */
+static int process_one_slice_vocoder(pvo *h) {
+    const int C = h->cfg.channels;
+    const int N = (int)h->N, hs = N / 2;
+    for (int c = 0; c < C; ++c) {
+        chan *a = &h->ch[c];
+        if (ring_readspace(&a->inbuf) < N) return -1;
+        int ready = ring_readspace(&a->inbuf);
+        ring_peek(&a->inbuf, a->frame_t, ready < N ? ready : N);
+        ring_discard(&a->inbuf, (int)h->hop);
+        analyze(h, a);
+    }
+    for (int c = 0; c < C; ++c) {
+        chan *a = &h->car[c];
+        int ready = ring_readspace(&a->inbuf);
+        ring_peek(&a->inbuf, a->frame_t, ready < N ? ready : N);
+        ring_discard(&a->inbuf, (int)h->hop);
+        analyze(h, a);
+    }
+    record_incr(h, h->hop, h->hop);
+    for (int c = 0; c < C; ++c) {
+        chan *ad = &h->ch[c], *ca = &h->car[c];
+        /* modifySliceVocoder: per band, carrier magnitude *= mean modulator magnitude */
+        int num_bands = 512;
+        int band_len = (int)floor((float)(h->N) / (float)(num_bands * 2));
+        for (int band_no = 0; band_no < num_bands; band_no++) {
+            float mean_modul_mag = 0;
+            for (int i = 0, j = band_no * band_len; i < band_len; i++, j++) mean_modul_mag += ad->mag[j];
+            mean_modul_mag /= (band_len * 2);
+            for (int i = 0, j = band_no * band_len; i < band_len; i++, j++) ca->mag[j] *= mean_modul_mag;
+            ca->mag[0] = 0;
+            ca->mag[hs] = 0;
+        }
+        /* synthesiseSliceCarrier */
+        float factor = 1.f / h->N;
+        for (int i = 0; i < hs + 1; ++i) ca->mag[i] *= factor;
+        rfft_inverse_polar(ca->fft, ca->mag, ca->phase, ca->frame_f);
+        for (int i = 0; i < hs; ++i) ca->frame_t[i] = ca->frame_f[i + hs];
+        for (int i = 0; i < hs; ++i) ca->frame_t[i + hs] = ca->frame_f[i];
+        for (int i = 0; i < N; ++i) ca->frame_t[i] *= h->win[i];
+        for (int i = 0; i < N; ++i) ca->oacc[i] += ca->frame_t[i];
+        float gain = h->win_area * 1.5;
+        for (int i = 0; i < N; ++i) ca->wacc[i] += h->win[i] * gain;
+        /* writeSliceCarrier */
+        const int s = (int)h->hop;
+        if (ring_writespace(&ca->outbuf) < s) {
+            fprintf(stderr, "pv_oracle: Buffer overrun on output for channel\n");
+            return 0;
+        }
+        for (int i = 0; i < s; ++i) ca->oacc[i] /= ca->wacc[i];
+        ring_write(&ca->outbuf, ca->oacc, s);
+        memmove(ca->oacc, ca->oacc + s, sizeof(float) * (N - s));
+        memset(ca->oacc + N - s, 0, sizeof(float) * s);
+        memmove(ca->wacc, ca->wacc + s, sizeof(float) * (N - s));
+        memset(ca->wacc + N - s, 0, sizeof(float) * s);
+        ad->slicecnt++;
+        ca->slicecnt++;
+    }
+    return 0;
+}
+
 int pvo_available(const pvo *h) {
     int ret = 0;
+    const chan *set = is_vocoder(h) ? h->car : h->ch;
     for (int c = 0; c < h->cfg.channels; ++c) {
-        int a = ring_readspace(&h->ch[c].outbuf);
+        int a = ring_readspace(&set[c].outbuf);
         if (c == 0 || a < ret) ret = a;
     }
     return ret;
@@ -1024,11 +1154,30 @@ int pvo_process(pvo *h, const float *const *in, int n) {
             size_t remaining = (size_t)n - nread[c];
             size_t writable = ring_writespace(&h->ch[c].inbuf);
             size_t towrite = remaining < writable ? remaining : writable;
+            if (is_vocoder(h)) {
+                /* enbufferChannelVocoder (phasevocoderprocess.cc:66-120): the carrier is generated in
+                 * lock-step with the samples written */
+                size_t cw = ring_writespace(&h->car[c].inbuf);
+                if (cw < towrite) towrite = cw;
+                float *ci = (float *)xcalloc(towrite ? towrite : 1, sizeof(float));
+                for (size_t i = 0; i < towrite; ++i) {
+                    if (h->cfg.mode == PVO_VOCODER_ROSENBERG) {
+                        ci[i] = rsb_next(&h->gen[c]) * 0.3;
+                    } else {
+                        float res = 0;
+                        for (int v = 0; v < 3; ++v) res += rsb_next(&h->chord[3 * c + v]) / 3;
+                        ci[i] = res * 0.3;
+                    }
+                }
+                ring_write(&h->car[c].inbuf, ci, (int)towrite);
+                free(ci);
+            }
             ring_write(&h->ch[c].inbuf, in[c] + nread[c], (int)towrite);
             nread[c] += towrite;
             allread = !(nread[c] < (size_t)n);
         }
         if (h->cfg.mode == PVO_CONSTANT) process_one_slice_constant(h);
+        else if (is_vocoder(h)) process_one_slice_vocoder(h);
         else process_one_slice(h);
     }
     free(nread);
@@ -1037,8 +1186,9 @@ int pvo_process(pvo *h, const float *const *in, int n) {
 
 int pvo_retrieve(pvo *h, float *const *out, int n) {
     int ret = n;
+    chan *set = is_vocoder(h) ? h->car : h->ch;
     for (int c = 0; c < h->cfg.channels; ++c) {
-        int got = ring_read(&h->ch[c].outbuf, out[c], ret);
+        int got = ring_read(&set[c].outbuf, out[c], ret);
         if (got < ret) ret = got;
     }
     return ret;

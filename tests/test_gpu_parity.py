@@ -267,7 +267,33 @@ def test_constant_realtime_api():
     assert rms(got, want) <= RMS_TOL
 
 
-def test_unsupported_modes_fail_loudly():
-    for mode in (E.VOCODER_ROSENBERG, E.VOCODER_CHORD):
+@pytest.mark.parametrize("kw", [dict(mode="vocoder"), dict(mode="vocoder_chord"), dict(mode="vocoder", fftsize=4096),
+                                dict(mode="vocoder_chord", fftsize=1024, sample_rate=44100)],
+                         ids=["rosenberg", "chord", "rosenberg4096", "chord1024"])
+def test_channel_vocoder_modes(kw):
+    """Rosenberg / chord carrier shaped by the band magnitudes of the input."""
+    import torch
+    x = signals.voice(30000, 2, seed=43)
+    want, wc, _ = O.run_offline(x, **kw)
+    got, gc = E.run_offline(x, **kw)
+    assert gc == wc and got.shape == want.shape
+    assert rms(got, want) <= RMS_TOL
+    bt = E.Batch(2, x.shape[1], channels=2, **kw)
+    out = bt.run(torch.from_numpy(np.stack([x, x])).cuda())
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    assert bits_equal(out[0], got) and bits_equal(out[1], got)
+
+
+def test_vocoder_realtime_api():
+    x = signals.voice(20000, 1, seed=44)
+    want, wc = O.run_realtime(x, mode="vocoder")
+    got, gc = E.run_realtime(x, mode="vocoder")
+    assert gc == wc
+    assert rms(got, want) <= RMS_TOL
+
+
+def test_invalid_modes_fail_loudly():
+    for mode in (8, 42, -2):
         with pytest.raises(E.PvError):
             E.PhaseVocoder(48000, 2, 1.0, 0.0, mode)

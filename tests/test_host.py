@@ -49,6 +49,8 @@ PLAN_CASES = [
     ([480] * 100, dict(channels=2, mode="constant")),
     ([480] * 100, dict(channels=2, mode="whisper")),
     ([333] * 100, dict(channels=1, mode="constant", fftsize=1024)),
+    ([480] * 100, dict(channels=2, mode="vocoder")),
+    ([480] * 100, dict(channels=2, mode="vocoder_chord", fftsize=4096)),
 ]
 
 
@@ -103,7 +105,7 @@ def test_errors():
     with pytest.raises(E.PvError):
         E.plan_simulate([480], channels=0, semitones=4.0)
     with pytest.raises(E.PvError):
-        E.plan_simulate([480], channels=2, mode="vocoder")
+        E.plan_simulate([480], channels=2, mode=42)
     with pytest.raises(E.PvError):  # output never retrieved: the reference's ring would overrun
         E.plan_simulate([100000], channels=2, semitones=-3.0)
 

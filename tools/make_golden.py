@@ -40,6 +40,8 @@ E2E = [
     ("rt_shift+4_cm1", "voice2", dict(api="rt", mode="normal_pitchshift", semitones=4.0, coremode=1, fftsize=2048)),
     ("constant_2048", "voice2", dict(mode="constant")),
     ("whisper_2048", "voice2", dict(mode="whisper")),
+    ("vocoder_rosenberg", "voice2", dict(mode="vocoder")),
+    ("vocoder_chord", "voice2", dict(mode="vocoder_chord")),
 ]
 
 
