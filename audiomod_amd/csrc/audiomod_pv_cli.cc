@@ -9,7 +9,8 @@
 //   audiomod-pv-exe normal_pitchshift  in.wav out.wav <semitones>  <coremode> <fftsize>
 //   audiomod-pv-exe formant_pitchshift in.wav out.wav <semitones>  <coremode> <fftsize>
 //   audiomod-pv-exe gender_change      in.wav out.wav <semitones>  <coremode> <fftsize>
-//   audiomod-pv-exe robotic            in.wav out.wav
+//   audiomod-pv-exe robotic | whisper | vocoder | vocoder_chord   in.wav out.wav
+//   audiomod-pv-exe constant           in.wav out.wav      (real-time processBlock loop, main.cc:561-572)
 // Effects of the reference that are not phase-vocoder modes are not provided here.
 #include <cstdint>
 #include <cstdio>
@@ -166,8 +167,8 @@ struct WavOut16 {
 
 int usage() {
     fprintf(stderr,
-            "usage: audiomod-pv-exe dafx_name infile outfile <args> (dafx: time_stretch, normal_pitchshift, "
-            "formant_pitchshift, gender_change, robotic)\n");
+            "usage: audiomod-pv-exe dafx_name infile outfile <args> (dafx: constant, time_stretch, normal_pitchshift, "
+            "formant_pitchshift, gender_change, vocoder, vocoder_chord, robotic, whisper)\n");
     return -1;
 }
 
@@ -190,8 +191,11 @@ int main(int argc, char **argv) {
             if (argc < 7) { fprintf(stderr, "err: not enough para (pitchshift_amount, coremode, fftsize)\n"); return -1; }
             const int mode = model == "normal_pitchshift" ? NORMAL_SHIFT : model == "formant_pitchshift" ? FORMANT_PRESERVE : GENDER_CHANGE;
             pv.reset(new audiomod::phasevocoder(sr, ch, 1, (float)atof(argv[4]), mode, atoi(argv[5]), atoi(argv[6])));
-        } else if (model == "robotic") {
-            pv.reset(new audiomod::phasevocoder(sr, ch, 1, 0, ROBOTIC));
+        } else if (model == "robotic" || model == "whisper" || model == "vocoder" || model == "vocoder_chord" ||
+                   model == "constant") {
+            const int mode = model == "robotic" ? ROBOTIC : model == "whisper" ? WHISPER : model == "vocoder" ? VOCODER_ROSENBERG
+                             : model == "vocoder_chord" ? VOCODER_CHORD : CONSTANT;
+            pv.reset(new audiomod::phasevocoder(sr, ch, 1, 0, mode));
         } else {
             fprintf(stderr, "fx not supported by the MI355X phase-vocoder driver: %s\n", model.c_str());
             return usage();
@@ -199,6 +203,18 @@ int main(int argc, char **argv) {
         modbase_offline *off = pv.get();
         WavOut16 out(argv[3], sr, ch);
         const int block = sr / 100 < 480 ? 480 : sr / 100; // main.cc:149
+        if (model == "constant") { // "everything else - real time application" (main.cc:560-572)
+            modbase *rt = pv.get();
+            std::vector<std::vector<float>> bs(ch, std::vector<float>(block));
+            std::vector<float *> buff(ch);
+            for (int c = 0; c < ch; ++c) buff[c] = bs[c].data();
+            for (long i = 0; i < file_length; i += block) {
+                const int n = in.read(buff.data(), block);
+                rt->processBlock(buff.data(), n);
+                if (rt->outputReady()) out.write(buff.data(), n);
+            }
+            return 0;
+        }
         std::vector<std::vector<float>> bs(ch, std::vector<float>(block)), os(ch, std::vector<float>(block * 4));
         std::vector<float *> buff(ch), outbuff(ch);
         for (int c = 0; c < ch; ++c) {

@@ -83,6 +83,8 @@ def main():
         ("time_stretch", ["1.5", "1", "4096"], "voice2"),
         ("gender_change", ["-7", "1", "2048"], "voice1"),
         ("robotic", [], "voice2"),
+        ("vocoder_chord", [], "voice2"),
+        ("constant", [], "voice1"),
     ]
     with tempfile.TemporaryDirectory() as d:
         for model, args, kind in wav_cases:
