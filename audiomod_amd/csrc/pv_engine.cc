@@ -125,7 +125,21 @@ struct Core {
     void launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
                       int ntiles, const int64_t *d_P, const float *d_wacc, const float *d_whisper,
                       const InAddr *carrier, float *out, int64_t out_stride_row, int64_t k_base,
-                      hipStream_t st, hipEvent_t *ev /* 2*PV_NUM_KERNELS events or null */) const;
+                      hipStream_t st, hipEvent_t *ev /* 2*PV_NUM_KERNELS events or null */,
+                      const OlaArgs *prev_ola = nullptr /* previous chunk's OLA, launched beside this chunk's chain */,
+                      OlaArgs *defer = nullptr /* receives this chunk's OLA instead of launching it */,
+                      hipStream_t st_chain = nullptr /* the chain's own stream (with ev_match / ev_chain) */,
+                      hipEvent_t ev_match = nullptr, hipEvent_t ev_chain = nullptr) const;
+    // Phase-locked batch path: the rotation chain of chunk i (a few waves per row, pure latency) runs on a second
+    // HIP stream while the main stream runs the overlap-add tiles of chunk i-1.
+    bool can_overlap_chain() const {
+        const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder;
+        // Off by default: measured on MI355X the chain runs 2.7x slower beside the overlap-add tiles (0.152 vs
+        // 0.055 ms per launch, whatever the stream / wave priority and prefetch depth) and the reordering costs the
+        // synthesis kernel its cache-warm inputs, so the overlapped pipeline is 5 % SLOWER end to end.
+        if (!getenv("AUDIOMOD_PV_OVERLAP_CHAIN")) return false;
+        return !bypass && d.cfg.coremode == 1;
+    }
 };
 
 int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
@@ -319,7 +333,8 @@ int Core::build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64
 void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
                         int ntiles, const int64_t *d_P, const float *d_wacc, const float *d_whisper,
                         const InAddr *carrier, float *out, int64_t out_stride_row, int64_t k_base,
-                        hipStream_t st, hipEvent_t *ev) const {
+                        hipStream_t st, hipEvent_t *ev, const OlaArgs *prev_ola, OlaArgs *defer,
+                        hipStream_t st_chain, hipEvent_t ev_match, hipEvent_t ev_chain) const {
     const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder;
     const int cm = bypass ? -1 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
     auto rec = [&](int i) {
@@ -402,9 +417,26 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         qa.st_kind = st_kind.p;
         qa.st_rot = st_rot.p;
         qa.st_po = st_po.p;
-        rec(2 * PV_K_SEQ);
-        launch_seq(qa, st);
-        rec(2 * PV_K_SEQ + 1);
+        if (st_chain && st_chain != st) {
+            // chain on its own stream: after this chunk's match, beside the previous chunk's overlap-add
+            (void)hipEventRecord(ev_match, st);
+            (void)hipStreamWaitEvent(st_chain, ev_match, 0);
+            if (ev) (void)hipEventRecord(ev[2 * PV_K_SEQ], st_chain);
+            launch_seq(qa, st_chain);
+            if (ev) (void)hipEventRecord(ev[2 * PV_K_SEQ + 1], st_chain);
+            (void)hipEventRecord(ev_chain, st_chain);
+            if (prev_ola && prev_ola->ntiles > 0) {
+                rec(2 * PV_K_OLA_RESAMPLE);
+                launch_ola(*prev_ola, st);
+                rec(2 * PV_K_OLA_RESAMPLE + 1);
+            }
+            (void)hipStreamWaitEvent(st, ev_chain, 0);
+        } else {
+            if (prev_ola && prev_ola->ntiles > 0) launch_ola(*prev_ola, st);
+            rec(2 * PV_K_SEQ);
+            launch_seq(qa, st);
+            rec(2 * PV_K_SEQ + 1);
+        }
     } else if (cm == 0) {
         PropArgs pa{};
         pa.N = d.N;
@@ -464,32 +496,34 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     launch_synth(sa, st);
     rec(2 * PV_K_SYNTH + 1);
 
-    if (ntiles > 0) {
-        OlaArgs oa{};
-        oa.N = d.N;
-        oa.rows = rows;
-        oa.FR = FR;
-        oa.frames = frames.p;
-        oa.tiles = d_tiles;
-        oa.P = d_P;
-        oa.ntiles = ntiles;
-        oa.resample = d.resample ? 1 : 0;
-        oa.interp = d.interp ? 1 : 0;
-        oa.num = d.res_num;
-        oa.den = d.res_den;
-        oa.filt_len = d.filt_len;
-        oa.oversample = d.oversample;
-        oa.sinc = sinc.p;
-        oa.tab4 = tab4.p;
-        oa.wacc = d_wacc;
-        oa.sinc_len = d.resample ? (int)d.sinc.size() : 0;
-        oa.lds_floats = ola_lds_floats;
-        oa.tab_bytes = !d.resample ? 0
-                       : d.interp  ? d.oversample * (d.filt_len + 1) * 16
-                                   : (int)((d.sinc.size() * sizeof(float) + 15) & ~(size_t)15);
-        oa.out = out;
-        oa.out_stride_row = out_stride_row;
-        oa.k_base = k_base;
+    OlaArgs oa{};
+    oa.N = d.N;
+    oa.rows = rows;
+    oa.FR = FR;
+    oa.frames = frames.p;
+    oa.tiles = d_tiles;
+    oa.P = d_P;
+    oa.ntiles = ntiles;
+    oa.resample = d.resample ? 1 : 0;
+    oa.interp = d.interp ? 1 : 0;
+    oa.num = d.res_num;
+    oa.den = d.res_den;
+    oa.filt_len = d.filt_len;
+    oa.oversample = d.oversample;
+    oa.sinc = sinc.p;
+    oa.tab4 = tab4.p;
+    oa.wacc = d_wacc;
+    oa.sinc_len = d.resample ? (int)d.sinc.size() : 0;
+    oa.lds_floats = ola_lds_floats;
+    oa.tab_bytes = !d.resample ? 0
+                   : d.interp  ? d.oversample * (d.filt_len + 1) * 16
+                               : (int)((d.sinc.size() * sizeof(float) + 15) & ~(size_t)15);
+    oa.out = out;
+    oa.out_stride_row = out_stride_row;
+    oa.k_base = k_base;
+    if (defer) {
+        *defer = oa; // launched later, beside the next chunk's chain
+    } else if (ntiles > 0) {
         rec(2 * PV_K_OLA_RESAMPLE);
         launch_ola(oa, st);
         rec(2 * PV_K_OLA_RESAMPLE + 1);
@@ -542,6 +576,8 @@ struct pv_batch {
     DevBuf<float> d_wacc;
     DevBuf<float> d_whisper; // WHISPER mode: [slices][C][HP] host-drawn phases, shared by all streams
     DevBuf<float> d_carrier; // vocoder modes: the carrier signal for every sample fed (incl. the zero flush)
+    hipStream_t chain_stream = nullptr; // second HIP stream for the rotation chain (phase-locked mode)
+    hipEvent_t ev_match[4] = {}, ev_chain[4] = {};
     int timing = 0; // 0 = off, n = instrument every n-th chunk
     std::vector<hipEvent_t> ev_pool; // kEvPerChunk per instrumented chunk
     std::vector<int> ev_chunk;       // chunk index of each used pool segment
@@ -550,6 +586,11 @@ struct pv_batch {
     int64_t acc_n[PV_NUM_KERNELS] = {};
     ~pv_batch() {
         for (auto e : ev_pool) (void)hipEventDestroy(e);
+        for (int i = 0; i < 4; ++i) {
+            if (ev_match[i]) (void)hipEventDestroy(ev_match[i]);
+            if (ev_chain[i]) (void)hipEventDestroy(ev_chain[i]);
+        }
+        if (chain_stream) (void)hipStreamDestroy(chain_stream);
     }
 };
 
@@ -681,6 +722,17 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
     if ((st = b->d_P.upload(P)) != PV_OK) return st;
     if ((st = b->d_tiles.upload(tiles)) != PV_OK) return st;
     if ((st = b->d_wacc.upload(wacc)) != PV_OK) return st;
+    if (c.can_overlap_chain()) {
+        // highest stream priority: the dispatcher must place the chain's few workgroups ahead of the thousands
+        // of overlap-add tiles queued on the main stream, or the chain only starts when the tiles are done
+        int prio_lo = 0, prio_hi = 0;
+        HIPC(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIPC(hipStreamCreateWithPriority(&b->chain_stream, hipStreamNonBlocking, prio_hi));
+        for (int i = 0; i < 4; ++i) {
+            HIPC(hipEventCreateWithFlags(&b->ev_match[i], hipEventDisableTiming));
+            HIPC(hipEventCreateWithFlags(&b->ev_chain[i], hipEventDisableTiming));
+        }
+    }
     if (c.d.vocoder) {
         CarrierGen gen((float)c.d.cfg.sample_rate, c.d.chord);
         std::vector<float> car((size_t)b->plan.in_frames);
@@ -746,6 +798,12 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
     car.stride_s = 0;
     car.mask = ~0ull;
     car.len = (int64_t)b->d_carrier.n;
+    // Software pipeline of the phase-locked path: the overlap-add of chunk i-1 is launched after the match of
+    // chunk i, so it runs while the second stream walks chunk i's rotation chain; the last chunk's overlap-add
+    // follows the loop.
+    const bool fused = b->chain_stream != nullptr;
+    OlaArgs pending{}, next_pending{};
+    pending.rows = c.rows;
     size_t ci = 0;
     for (const auto &ch : b->chunks) {
         hipEvent_t *ev = nullptr;
@@ -763,9 +821,13 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
         c.launch_chunk(ia, ch.t0, ch.Tn, b->d_pinc.p + ch.t0, b->d_tiles.p + ch.tile_begin, ch.ntiles, b->d_P.p,
                        b->d_wacc.p + (size_t)ch.tile_begin * c.ola_lds_floats,
                        b->d_whisper.p ? b->d_whisper.p + (size_t)ch.t0 * c.C * c.HP : nullptr,
-                       c.d.vocoder ? &car : nullptr, d_out, b->plan.out_frames, 0, st, ev);
+                       c.d.vocoder ? &car : nullptr, d_out, b->plan.out_frames, 0, st, ev,
+                       fused ? &pending : nullptr, fused ? &next_pending : nullptr, b->chain_stream,
+                       b->ev_match[ci & 3], b->ev_chain[ci & 3]);
+        if (fused) pending = next_pending;
         ++ci;
     }
+    if (fused && pending.ntiles > 0) launch_ola(pending, st);
     HIPC(hipGetLastError());
     return PV_OK;
 }
@@ -777,11 +839,14 @@ int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launch
     const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder;
     const int cm = bypass ? -1 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
     for (size_t i = 0; i + kEvPerChunk <= b->ev_used; i += kEvPerChunk) {
-        const auto &ch = b->chunks[(size_t)b->ev_chunk[i / kEvPerChunk]];
         for (int k = 0; k < PV_NUM_KERNELS; ++k) {
             if ((k == PV_K_MATCH || k == PV_K_SEQ) && cm != 1) continue;
             if (k == PV_K_PROP && cm != 0) continue;
-            if (k == PV_K_OLA_RESAMPLE && ch.ntiles == 0) continue;
+            if (k == PV_K_OLA_RESAMPLE) {
+                // with the chain on its own stream the OLA events of chunk i bracket chunk i-1's overlap-add
+                const int ci2 = b->ev_chunk[i / kEvPerChunk] - (b->chain_stream ? 1 : 0);
+                if (ci2 < 0 || b->chunks[(size_t)ci2].ntiles == 0) continue;
+            }
             float t = 0;
             if (hipEventElapsedTime(&t, b->ev_pool[i + 2 * k], b->ev_pool[i + 2 * k + 1]) == hipSuccess) {
                 b->acc_ms[k] += t;

@@ -9,7 +9,7 @@
 namespace pv {
 
 constexpr int kFftThreads = 256;   // workgroup size of the analysis / synthesis kernels (4 waves)
-constexpr int kTileOut = 256;      // outputs per workgroup of the OLA+resample kernel
+constexpr int kTileOut = 256;      // outputs (= threads) per workgroup of the OLA+resample kernel
 constexpr int kMaxTileFrames = 64; // frames that can overlap one OLA tile (checked on the host)
 
 struct DevTables {

@@ -504,13 +504,12 @@ __device__ __forceinline__ int region_of(const uint16_t *pk, int n, int i) {
     return lo;
 }
 
-__global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+__device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *smem_raw) {
     float *srot0 = reinterpret_cast<float *>(smem_raw);          // [PKP]
     float *srot1 = srot0 + a.PKP;                                // [PKP]
     float *spo = srot1 + a.PKP;                                  // [hs] full prev_out (valid when kind == 1)
     uint16_t *spk = reinterpret_cast<uint16_t *>(spo + a.hs);    // [PKP] peaks of the previous same-row step
-    const int row = blockIdx.x, nt = blockDim.x, tid = threadIdx.x, hs = a.hs;
+    const int nt = blockDim.x, tid = threadIdx.x, hs = a.hs;
     const int c = row % a.C;
     int kind = a.st_kind[row];
     float *rprev = srot0, *rcur = srot1;
@@ -535,13 +534,11 @@ __global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
     // unconditional (index clamped): a load inside an exec-masked branch gets its s_waitcnt at the end of
     // the branch, which would defeat the prefetch
     const int rix = tid < a.PKP ? tid : a.PKP - 1;
-    // prefetch one step ahead (deeper queues measured slower: the chain, not the load latency, bounds a step)
-    constexpr int kDepth = 1;
-    auto ld_hdr = [&](int tl) -> uint32_t { // always loads (clamped): keeps the VMEM count per iteration static
-        const uint32_t v = a.recs[plane_of(tl < a.Tn ? tl : a.Tn - 1) * a.PKP + a.PKP - 1 + vz].p1r1;
-        return tl < a.Tn ? v : 3u; // 3 = sentinel, ends the loops
-    };
-    auto ld_rec = [&](int tl) -> PeakRec { return a.recs[plane_of(tl < a.Tn ? tl : a.Tn - 1) * a.PKP + rix]; };
+    // Prefetch ONE step ahead.  Measured alternatives (all slower alone on the GPU): queues 4 and 6 steps deep
+    // (+15 %: the chain, not the load latency, bounds a step), always-clamped loads instead of the uniform
+    // last-step branch (+13 %).
+    auto ld_hdr = [&](int tl) -> uint32_t { return a.recs[plane_of(tl) * a.PKP + a.PKP - 1 + vz].p1r1; };
+    auto ld_rec = [&](int tl) -> PeakRec { return a.recs[plane_of(tl) * a.PKP + rix]; };
     uint32_t h0 = ld_hdr(0);
     PeakRec q0 = ld_rec(0);
 
@@ -553,19 +550,23 @@ __global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
         while (tl < a.Tn && (h0 & 3u) == (uint32_t)kModeLock && one_pass) {
             const int64_t plane = plane_of(tl);
             const PeakRec r = q0;
-            // fetch the next step (two loads, always)
-            h0 = ld_hdr(tl + kDepth);
-            q0 = ld_rec(tl + kDepth);
+            if (tl + 1 < a.Tn) { // uniform branch
+                h0 = ld_hdr(tl + 1);
+                q0 = ld_rec(tl + 1);
+            } else {
+                h0 = 3u; // sentinel: leaves both loops
+            }
             // Branch-free over the lanes: lanes beyond the peak count run on whatever their (clamped) record
             // slot holds and write slots nobody reads.
             const uint32_t r1 = min(r.p1r1 >> 16, (uint32_t)(a.PKP - 1));
             const uint32_t p1 = (r.p1r1 & 0xffffu) & (uint32_t)(hs - 1);
-            float po;
-            if (kind == 2) po = (float)princarg((double)(r.a1 + rprev[r1]));
-            else if (kind == 1) po = spo[p1];
-            else po = 0.f;
-            const float tgt = (float)princarg((double)(po + r.adv));
-            const float rt = (float)princarg((double)(tgt - r.a2));
+            // straight-line code (princarg_div has no rare-case branch): any branch inside this loop makes the
+            // compiler fall back to vmcnt(0) at the joins, which exposes the store latency under load
+            const float po_lock = (float)princarg_div((double)(r.a1 + rprev[r1]));
+            const float po_full = spo[p1];
+            const float po = kind == 2 ? po_lock : (kind == 1 ? po_full : 0.f);
+            const float tgt = (float)princarg_div((double)(po + r.adv));
+            const float rt = (float)princarg_div((double)(tgt - r.a2));
             rcur[rix] = rt;
             a.rot[plane * a.PKP + rix] = rt;
             kind = 2;
@@ -580,8 +581,10 @@ __global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
         const int64_t t = a.t0 + tl;
         const int64_t plane = plane_of(tl);
         const int mode = (int)(h0 & 3u), n = (int)(h0 >> 2);
-        h0 = ld_hdr(tl + kDepth);
-        q0 = ld_rec(tl + kDepth);
+        if (tl + 1 < a.Tn) {
+            h0 = ld_hdr(tl + 1);
+            q0 = ld_rec(tl + 1);
+        }
         if (mode == kModeLock) {
             for (int p = tid; p < n; p += nt) {
                 const PeakRec r = a.recs[plane * a.PKP + p];
@@ -644,11 +647,25 @@ __global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
     (void)c;
 }
 
-void launch_seq(const SeqArgs &a, hipStream_t st) {
-    int nt = (a.PKP + 63) & ~63;
+__global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // the chain is pure latency and may share the GPU with the overlap-add tiles of the previous chunk (second
+    // HIP stream): let its few waves win every issue arbitration
+    __builtin_amdgcn_s_setprio(3);
+    seq_role(a, blockIdx.x, smem_raw);
+}
+
+int seq_threads(int PKP) {
+    int nt = (PKP + 63) & ~63;
     if (nt > 1024) nt = 1024;
     if (nt < 64) nt = 64;
-    const size_t lds = sizeof(float) * ((size_t)2 * a.PKP + a.hs) + sizeof(uint16_t) * a.PKP;
+    return nt;
+}
+size_t seq_lds_bytes(const SeqArgs &a) { return sizeof(float) * ((size_t)2 * a.PKP + a.hs) + sizeof(uint16_t) * a.PKP; }
+
+void launch_seq(const SeqArgs &a, hipStream_t st) {
+    const int nt = seq_threads(a.PKP);
+    const size_t lds = seq_lds_bytes(a);
     static bool big = false;
     allow_big_lds(pv_seq_kernel, big);
     hipLaunchKernelGGL(pv_seq_kernel, dim3(a.rows), dim3(nt), lds, st, a);
@@ -1069,8 +1086,7 @@ void launch_synth(const SynthArgs &a, hipStream_t st) {
 // --------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(kTileOut) void pv_ola_kernel(const OlaArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+__device__ __forceinline__ void ola_role(const OlaArgs &a, const int tile_i, const int row, char *smem_raw) {
     // interpolated mode: coefficient table expanded per sub-sample offset, tab4[off][j] = the four taps
     // sinc[4 + (j+1)*ov - off + {-2,-1,0,1}] of resampler_basic_interpolate_single (resample.c:494-535) as one
     // aligned float4; rows are padded to NF+1 slots so the (at most ov) distinct rows a wave reads in one
@@ -1079,7 +1095,7 @@ __global__ __launch_bounds__(kTileOut) void pv_ola_kernel(const OlaArgs a) {
     float *stab = reinterpret_cast<float *>(smem_raw);
     float *ola = reinterpret_cast<float *>(smem_raw + a.tab_bytes);   // [lds_floats]
     int *sP = reinterpret_cast<int *>(ola + a.lds_floats);            // [kMaxTileFrames] P_t - n_lo
-    const int tile_i = blockIdx.x, row = blockIdx.y, nt = blockDim.x, tid = threadIdx.x;
+    const int nt = blockDim.x, tid = threadIdx.x;
     const OlaTile tile = a.tiles[tile_i];
     const int N = a.N, NF = a.filt_len;
 
@@ -1158,8 +1174,17 @@ __global__ __launch_bounds__(kTileOut) void pv_ola_kernel(const OlaArgs a) {
     }
 }
 
+__global__ __launch_bounds__(kTileOut) void pv_ola_kernel(const OlaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    ola_role(a, blockIdx.x, blockIdx.y, smem_raw);
+}
+
+size_t ola_lds_bytes(const OlaArgs &a) {
+    return (size_t)a.tab_bytes + sizeof(float) * (size_t)a.lds_floats + sizeof(int) * kMaxTileFrames;
+}
+
 void launch_ola(const OlaArgs &a, hipStream_t st) {
-    const size_t lds = (size_t)a.tab_bytes + sizeof(float) * (size_t)a.lds_floats + sizeof(int) * kMaxTileFrames;
+    const size_t lds = ola_lds_bytes(a);
     static bool big = false;
     allow_big_lds(pv_ola_kernel, big);
     hipLaunchKernelGGL(pv_ola_kernel, dim3(a.ntiles, a.rows), dim3(kTileOut), lds, st, a);
