@@ -35,3 +35,8 @@ CLI := audiomod_amd/lib/audiomod-pv-exe
 $(CLI): audiomod_amd/csrc/audiomod_pv_cli.cc $(LIB) include/dafx/phasevocoder.h include/dafx/modbase.h
 	$(HIPCC) -O2 -std=c++17 -Iinclude -Iinclude/dafx audiomod_amd/csrc/audiomod_pv_cli.cc -Laudiomod_amd/lib -laudiomod_pv -Wl,-rpath,'$$ORIGIN' -o $@
 all: $(SHIM) $(CLI)
+
+SBENCH := audiomod_amd/lib/stream_bench
+$(SBENCH): tools/stream_bench.cc $(LIB) include/dafx/phasevocoder.h
+	$(HIPCC) -O2 -std=c++17 -Iinclude -Iinclude/dafx tools/stream_bench.cc -Laudiomod_amd/lib -laudiomod_pv -Wl,-rpath,'$$ORIGIN' -o $@
+all: $(SBENCH)
