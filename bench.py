@@ -25,6 +25,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+CONFIGS = {  # BASELINE.json configs[1..3]; configs[4] is cfg2 at 128 streams per GPU x 8 GPUs (the default workload)
+    "cfg2": ("configs[1]: normal_pitchshift +4 st, stereo 48 kHz, fft=2048",
+             dict(mode="normal_pitchshift", semitones=4.0, fftsize=2048), True),
+    "cfg3": ("configs[2]: time_stretch ratio=1.5, stereo 48 kHz, fft=4096",
+             dict(mode="time_stretch", time_ratio=1.5, fftsize=4096), False),
+    "cfg4_formant+7": ("configs[3]: formant_pitchshift +7 st, stereo 48 kHz, fft=2048",
+                       dict(mode="formant_pitchshift", semitones=7.0, fftsize=2048), True),
+    "cfg4_formant-7": ("configs[3]: formant_pitchshift -7 st, stereo 48 kHz, fft=2048",
+                       dict(mode="formant_pitchshift", semitones=-7.0, fftsize=2048), True),
+    "cfg4_gender+7": ("configs[3]: gender_change +7 st, stereo 48 kHz, fft=2048",
+                      dict(mode="gender_change", semitones=7.0, fftsize=2048), True),
+    "cfg4_gender-7": ("configs[3]: gender_change -7 st, stereo 48 kHz, fft=2048",
+                      dict(mode="gender_change", semitones=-7.0, fftsize=2048), True),
+}
+
+
 def make_input(torch, streams, frames, device, rank):
     """Synthetic 48 kHz stereo on the int16 grid: a few host-synthesised voices, varied per stream on the GPU."""
     from audiomod_amd import signals
@@ -77,6 +93,8 @@ def main():
     ap.add_argument("--streams", type=int, default=128, help="stereo streams per GPU (cfg5: 1024 / 8)")
     ap.add_argument("--seconds", type=int, default=20, help="audio seconds per stream per step")
     ap.add_argument("--coremode", type=int, default=1)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS),
+                    help="BASELINE config to run (default cfg2 = configs[1], the one the metric is quoted on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsals)")
     ap.add_argument("--force-device", type=int, default=-1, help="use this device on every rank (rehearsals only)")
@@ -108,12 +126,13 @@ def main():
     from audiomod_amd import engine as E
     from audiomod_amd.sharding import max_over_ranks
     frames = args.seconds * 48000
-    kw = dict(mode="normal_pitchshift", semitones=4.0, coremode=args.coremode, fftsize=2048)
+    cfg_name, cfg_kw, cfg_flush = CONFIGS[args.config]
+    kw = dict(coremode=args.coremode, **cfg_kw)
     G = max(1, args.groups)
     assert args.streams % G == 0, "--streams must be a multiple of --groups"
     d_in = make_input(torch, args.streams, frames, device, rank)
     per = args.streams // G
-    batches = [E.Batch(per, frames, channels=2, block=480, flush=True, device=local_rank, **kw) for _ in range(G)]
+    batches = [E.Batch(per, frames, channels=2, block=480, flush=cfg_flush, device=local_rank, **kw) for _ in range(G)]
     ins = [d_in[g * per:(g + 1) * per] for g in range(G)]
     outs = [b.alloc_out() for b in batches]
     hip_streams = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device) for _ in range(G - 1)]
@@ -153,6 +172,7 @@ def main():
         slices_per_step_gpu = batch.slices * 2 * args.streams
         slices_per_launch = batch.slices * 2 * per / batch.launches  # one launch = one chunk of one group
         N, H, s, h = info["fftsize"], info["fftsize"] // 2 + 1, info["hop_out_nominal"], info["hop_in"]
+        rs = 1 if info["resample"] else 0  # without resampling SURVEY 8(d) drops the s + h terms
         # Algorithmic bytes per slice of each pipeline stage; they sum to SURVEY 8(d)'s
         # B_slice = 4*(3N+7H+2s+h).  The phase stage runs as two kernels (match + seq) in phase-locked
         # mode and as one (prop) in coremode 0; a stage's time is the sum over its kernels.
@@ -160,7 +180,7 @@ def main():
             "analysis": (4 * (N + 2 * H), ["pv_analyze_kernel"]),
             "phase": (4 * (3 * H), ["pv_match_kernel", "pv_seq_kernel", "pv_prop_kernel"]),
             "synthesis": (4 * (2 * H + N), ["pv_synth_kernel"]),
-            "ola_resample": (4 * (N + 2 * s + h), ["pv_ola_kernel"]),
+            "ola_resample": (4 * (N + s + rs * (s + h)), ["pv_ola_kernel"]),
         }
         assert sum(b for b, _ in stages.values()) == info["bytes_per_slice"]
         per_kernel, per_stage = {}, {}
@@ -181,7 +201,7 @@ def main():
         dom_stage = max(per_stage, key=lambda k: per_stage[k]["avg_ms"])
         dom = max(per_stage[dom_stage]["kernels"], key=lambda k: per_kernel[k]["avg_ms"])
         achieved = per_stage[dom_stage]["GBps"]
-        traffic = traffic_db.get(dom) if (G == 1 and args.streams == 128) else None
+        traffic = traffic_db.get(dom) if (G == 1 and args.streams == 128 and args.config == "cfg2") else None
         pipeline_gbps = info["bytes_per_slice"] * slices_per_step_gpu * args.steps / dt / 1e9
         line = {
             "metric": "Msamples/s (48 kHz stereo) phase-vocoder pitch-shift; x real-time per GPU",
@@ -189,8 +209,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "x_realtime_per_gpu": round(xrt_gpu, 1),
-            "config": {"workload": "configs[1]: normal_pitchshift +4 st, stereo 48 kHz, fft=2048, phase-locked"
-                                   if args.coremode == 1 else f"configs[1] with coremode {args.coremode}",
+            "config": {"workload": cfg_name + (", phase-locked" if args.coremode == 1 else f", coremode {args.coremode}"),
                        "streams_per_gpu": args.streams, "seconds_per_stream": args.seconds, "channels": 2,
                        "block": 480, "hop_in": h, "slices_per_channel": int(batch.slices),
                        "concurrent_stream_groups": G, "launches_per_step": int(batch.launches) * G,
@@ -201,7 +220,7 @@ def main():
                          "pipeline_GBps": round(pipeline_gbps, 1), "per_stage": per_stage,
                          "per_kernel": per_kernel},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -293,6 +293,31 @@ def test_vocoder_realtime_api():
     assert rms(got, want) <= RMS_TOL
 
 
+FULL = [
+    ("cfg3", dict(mode="time_stretch", time_ratio=1.5, coremode=1, fftsize=4096, flush=False)),
+    ("cfg4_formant+7", dict(mode="formant_pitchshift", semitones=7.0, coremode=1, fftsize=2048)),
+    ("cfg4_gender-7", dict(mode="gender_change", semitones=-7.0, coremode=1, fftsize=2048)),
+]
+
+
+@pytest.mark.parametrize("name,kw", FULL, ids=[n for n, _ in FULL])
+def test_full_size_other_baseline_configs(name, kw):
+    """BASELINE configs[2] and configs[3] at full length (60 s stereo) on one stream of a 2-stream batch."""
+    import torch
+    F = 60 * 48000
+    x = np.tile(signals.voice(4 * 48000, 2, seed=17), (1, 15))
+    kw = dict(kw)
+    flush = kw.pop("flush", True)
+    want, _, _ = O.run_offline(x, flush=flush, **kw)
+    bt = E.Batch(2, F, channels=2, flush=flush, **kw)
+    out = bt.run(torch.from_numpy(np.stack([x, x])).cuda())
+    torch.cuda.synchronize()
+    y = out.cpu().numpy()
+    assert y[0].shape == want.shape
+    assert rms(y[0], want) <= RMS_TOL
+    assert bits_equal(y[0], y[1])
+
+
 def test_invalid_modes_fail_loudly():
     for mode in (8, 42, -2):
         with pytest.raises(E.PvError):
