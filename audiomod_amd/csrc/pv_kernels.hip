@@ -56,6 +56,14 @@ __device__ __forceinline__ double princarg(double a) {
     return (x - (y * n)) + PV_PI;
 }
 
+__device__ __forceinline__ void wave_sync() {
+    // LDS operations of one wave execute in issue order; this only stops the compiler from moving LDS
+    // accesses across the hand-off between two passes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // the plain reference expression (one IEEE divide): lower latency when a single dependent chain is all there is
 __device__ __forceinline__ double princarg_div(double a) {
     const double x = a + PV_PI;
@@ -232,14 +240,6 @@ __global__ __launch_bounds__(kFftThreads) void pv_analyze_kernel(const AnalyzeAr
 // analysis, wave-per-frame variant (N = 2048 / 4096): one 64-lane wave owns a slice, the four waves of a
 // workgroup take four consecutive slices of the same row.  No workgroup barrier anywhere.
 // --------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_sync() {
-    // LDS operations of one wave execute in issue order; this only stops the compiler from moving LDS
-    // accesses across the hand-off between two passes
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 __device__ __forceinline__ bool block_to_row_slice4(int Tn, int rows, int &row, int &tl) {
     const int groups = (Tn + 3) >> 2;
     const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
@@ -400,14 +400,46 @@ void launch_analyze(const AnalyzeArgs &a, hipStream_t st) {
 // (the reference's Impl-member quirk, phasevocoderimpl.h:236-238): the "previous
 // peaks" of step (t, c) are those of (t, c-1), or of (t-1, C-1) when c == 0.
 // --------------------------------------------------------------------------------------------
-constexpr int kMatchThreads = 128;
+constexpr int kMatchThreads = 256; // four waves, one step (slice) each: no workgroup barrier
+
+// nearest set bit to position p in a bitmap of nw 64-bit words (ties -> the lower position); -1 if none
+__device__ __forceinline__ int nearest_set_bit(const unsigned long long *bm, int nw, int p) {
+    const int w = p >> 6, b = p & 63;
+    int up = -1, dn = -1;
+    unsigned long long m = bm[w] & (~0ull << b);
+    for (int i = w; i < nw; ++i) {
+        if (i != w) m = bm[i];
+        if (m) {
+            up = i * 64 + __ffsll((long long)m) - 1;
+            break;
+        }
+    }
+    m = b ? (bm[w] & ((1ull << b) - 1ull)) : 0ull;
+    for (int i = w; i >= 0; --i) {
+        if (i != w) m = bm[i];
+        if (m) {
+            dn = i * 64 + 63 - __clzll((long long)m);
+            break;
+        }
+    }
+    if (up < 0) return dn;
+    if (dn < 0) return up;
+    return (up - p) < (p - dn) ? up : dn;
+}
 
 __global__ __launch_bounds__(kMatchThreads) void pv_match_kernel(const MatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    uint16_t *scur = reinterpret_cast<uint16_t *>(smem_raw); // [PKP]
-    uint16_t *sprev = scur + a.PKP;                          // [PKP] peaks of the previous step (other channel)
-    uint16_t *ssame = sprev + a.PKP;                         // [PKP] peaks of the previous slice, same channel
-    const int tl = blockIdx.x, row = blockIdx.y, nt = blockDim.x, tid = threadIdx.x;
+    // bitmaps instead of sorted-list searches: "nearest previous peak" is a find-first-set around p2 in the
+    // previous step's peak bitmap; "region of p1" is a prefix popcount over the boundary bitmap of the previous
+    // same-channel step (2-4 independent LDS reads instead of two 9-step dependent binary searches)
+    const int nw = (a.hs + 63) >> 6;
+    const int wave = threadIdx.x >> 6;
+    char *wbase = smem_raw + (size_t)wave * (sizeof(unsigned long long) * 2 * nw + sizeof(int) * nw + 8);
+    unsigned long long *bprev = reinterpret_cast<unsigned long long *>(wbase);    // [nw] peaks of the previous step
+    unsigned long long *bbnd = bprev + nw;                                        // [nw] region boundaries, same channel
+    int *pre = reinterpret_cast<int *>(bbnd + nw);                                // [nw] boundaries before each word
+    const int tl = blockIdx.x * 4 + wave, row = blockIdx.y, nt = 64, tid = threadIdx.x & 63;
+    if (tl >= a.Tn) return; // wave-uniform
     const int s = row / a.C, c = row - s * a.C;
     const int64_t t = a.t0 + tl;
     const int slot = ring_slot(a.s0, tl, a.TR), pslot = ring_prev(slot, a.TR);
@@ -430,28 +462,32 @@ __global__ __launch_bounds__(kMatchThreads) void pv_match_kernel(const MatchArgs
     if (mode != kModeLock) return;
     const int64_t splane = t > 0 ? (int64_t)row * a.TR + pslot : -1;
     const int nsame = splane >= 0 ? a.npk[splane] : 0;
-    for (int i = tid; i < ncur; i += nt) scur[i] = a.peaks[plane * a.PKP + i];
-    for (int i = tid; i < nprev; i += nt) sprev[i] = a.peaks[pplane * a.PKP + i];
-    for (int i = tid; i < nsame; i += nt) ssame[i] = a.peaks[splane * a.PKP + i];
-    __syncthreads();
+    for (int i = tid; i < 2 * nw; i += nt) bprev[i] = 0ull; // bprev and bbnd are adjacent
+    wave_sync();
+    unsigned int *bprev32 = reinterpret_cast<unsigned int *>(bprev), *bbnd32 = reinterpret_cast<unsigned int *>(bbnd);
+    for (int i = tid; i < nprev; i += nt) {
+        const int b = a.peaks[pplane * a.PKP + i];
+        atomicOr(&bprev32[b >> 5], 1u << (b & 31));
+    }
+    for (int i = tid; i + 1 < nsame; i += nt) {
+        const int b = ((int)a.peaks[splane * a.PKP + i] + (int)a.peaks[splane * a.PKP + i + 1] + 1) >> 1;
+        atomicOr(&bbnd32[b >> 5], 1u << (b & 31));
+    }
+    wave_sync();
+    if (tid < nw) {
+        int acc = 0;
+        for (int i = 0; i < tid; ++i) acc += __popcll(bbnd[i]);
+        pre[tid] = acc;
+    }
+    wave_sync();
     const float *__restrict__ A2 = a.phase + plane * a.HP;
     const float *__restrict__ A1 = splane >= 0 ? a.phase + splane * a.HP : nullptr;
     const float pinc_f = (float)a.phase_inc[tl], hop_f = (float)a.hop;
     const double Nd = (double)a.N;
     for (int p = tid; p < ncur; p += nt) {
-        const int p2 = scur[p];
-        // nearest previous peak, ties -> lower index (== the reference's monotone greedy walk :644-652)
-        int lo = 0, hi = nprev;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if ((int)sprev[mid] < p2) lo = mid + 1;
-            else hi = mid;
-        }
-        int sel;
-        if (lo == 0) sel = 0;
-        else if (lo == nprev) sel = nprev - 1;
-        else sel = ((int)sprev[lo] - p2) < (p2 - (int)sprev[lo - 1]) ? lo : lo - 1;
-        const int p1 = sprev[sel];
+        const int p2 = a.peaks[plane * a.PKP + p];
+        // nearest previous peak, ties -> lower bin (== the reference's monotone greedy walk :644-652)
+        const int p1 = nearest_set_bit(bprev, nw, p2);
         const float avg_p = (float)((double)(p1 + p2) * 0.5);
         const float pomega = (float)((a.two_pi_hop * (double)(avg_p - 1)) / Nd);
         const float a2 = A2[p2];
@@ -459,17 +495,9 @@ __global__ __launch_bounds__(kMatchThreads) void pv_match_kernel(const MatchArgs
         const float d1 = a2 - a1 - pomega;
         const float pdelta = (float)((double)pomega + princarg((double)d1));
         // region of p1 in the previous same-channel step = number of its boundaries <= p1
-        int r1 = 0;
-        if (nsame > 1) {
-            int l2 = 0, h2 = nsame - 1;
-            while (l2 < h2) {
-                const int mid = (l2 + h2) >> 1;
-                const int bnd = ((int)ssame[mid] + (int)ssame[mid + 1] + 1) >> 1;
-                if (bnd <= p1) l2 = mid + 1;
-                else h2 = mid;
-            }
-            r1 = l2;
-        }
+        const int w1 = p1 >> 6, b1 = p1 & 63;
+        const unsigned long long le = b1 == 63 ? ~0ull : ((2ull << b1) - 1ull);
+        const int r1 = pre[w1] + __popcll(bbnd[w1] & le);
         PeakRec r;
         r.adv = (pdelta * pinc_f) / hop_f;
         r.a2 = a2;
@@ -480,8 +508,9 @@ __global__ __launch_bounds__(kMatchThreads) void pv_match_kernel(const MatchArgs
 }
 
 void launch_match(const MatchArgs &a, hipStream_t st) {
-    const size_t lds = sizeof(uint16_t) * 3 * a.PKP;
-    hipLaunchKernelGGL(pv_match_kernel, dim3(a.Tn, a.rows), dim3(kMatchThreads), lds, st, a);
+    const int nw = (a.hs + 63) >> 6;
+    const size_t lds = 4 * (sizeof(unsigned long long) * 2 * nw + sizeof(int) * nw + 8);
+    hipLaunchKernelGGL(pv_match_kernel, dim3((a.Tn + 3) / 4, a.rows), dim3(kMatchThreads), lds, st, a);
 }
 
 // --------------------------------------------------------------------------------------------
