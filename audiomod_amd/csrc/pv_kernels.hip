@@ -71,6 +71,18 @@ __device__ __forceinline__ double princarg_div(double a) {
     return (x - (y * floor(x / y))) + PV_PI;
 }
 
+// princarg where the argument is the sum or difference of two wrapped phases (|a| <= 2 pi + a few float ulp):
+// floor((a + pi) / (-2 pi)) can only be 0, -1 or -2, and which one follows from comparing x = a + pi with 0 and
+// 2 pi -- the correctly rounded quotient x / y lies on the same side of 0 and -1 as the exact one (x / 2 pi differs
+// from 1 by at least ulp(x) / 2 pi = 1.4e-16, more than half the spacing of doubles around 1) -- and y * n is exact
+// for these n.  Bit-identical to princarg_div without the divide (tests/native/host_princarg.cc sweeps it).
+__device__ __forceinline__ double princarg_small(double a) {
+    const double x = a + PV_PI;
+    const double Y = 2.0 * PV_PI;
+    const double yn = x > 0.0 ? (x > Y ? 2.0 * Y : Y) : 0.0;
+    return (x - yn) + PV_PI;
+}
+
 // XCD-aware block -> (row, slice) map: blocks b and b+8 share an XCD (and its L2), so each XCD walks
 // whole rows (one stream-channel) slice after slice and re-reads the overlapping input from its own L2.
 __device__ __forceinline__ int ring_slot(int s0, int tl, int TR) {
@@ -265,34 +277,72 @@ template <int NC> __global__ __launch_bounds__(256) void pv_analyze_wave_kernel(
     const cf *__restrict__ tw = reinterpret_cast<const cf *>(tb.tw_fwd);
     const cf *__restrict__ stw = reinterpret_cast<const cf *>(tb.st_fwd);
 
+    // Every global load below is issued ahead of its use, as early as the 128-VGPR budget of four waves per SIMD
+    // allows (a pass's twiddles while the previous pass finishes, the split's super-twiddles during the last pass,
+    // all of them before the first store): a load placed at its use costs the wave a full memory round trip, and one
+    // placed after a store also waits for that store to be acknowledged (vmcnt is a single in-order counter).
+    WfTw<W> T0, T1, T2;
+    wf_load_pass_tw<W, 0>(T0, lane, tw);
     // windowed, fft-shifted frame straight into the pass-0 register layout: for a fixed register the 64
     // lanes read one contiguous 512-byte span of the input (permuted among the lanes)
     cf v[R];
     {
         const int lp = wf_lane_part<W>(0, lane);
         const int lsrc = wf_src_of<W>(lp);
+        const uint64_t m0 = (uint64_t)a0 & a.ia.mask;
+        if (a0 + N <= a.ia.len && ((m0 + (uint64_t)(N - 1)) & a.ia.mask) == m0 + (uint64_t)(N - 1)) {
+            // the whole frame lies inside the input and does not wrap the ring (wave-uniform, the common
+            // case): one base pointer, 32-bit lane offsets, no per-sample bounds checks
+            const float *__restrict__ fb = in + m0;
+            const int kl = (2 * lsrc + hs) & (N - 1); // the register part only sets bits the lane part leaves clear
+            int kl1 = kl + 1;                // kept opaque: a0 may be odd, and a merged 8-byte load of an odd-aligned
+            asm volatile("" : "+v"(kl1));    // sample pair is slower than two 4-byte loads
+            float2 ww[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int src = lsrc | wf_src_of_const<W>(wf_reg_part<W>(0, r));
-            const int k0 = (2 * src + hs) & (N - 1);
-            const int64_t g0 = a0 + k0;
-            const float x0 = g0 < a.ia.len ? in[(uint64_t)g0 & a.ia.mask] : 0.f;
-            const float x1 = g0 + 1 < a.ia.len ? in[(uint64_t)(g0 + 1) & a.ia.mask] : 0.f;
-            v[r] = cf{x0 * w[k0], x1 * w[k0 + 1]};
+            for (int r = 0; r < R; ++r) {
+                const int kr = 2 * wf_src_of_const<W>(wf_reg_part<W>(0, r)); // < hs, disjoint from lsrc's bits
+                const int k0 = kl ^ kr;                                      // == (2 * (lsrc | src_r) + hs) & (N - 1)
+                ww[r] = *reinterpret_cast<const float2 *>(w + k0);
+                v[r] = cf{fb[k0], fb[kl1 ^ kr]};
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = cf{v[r].x * ww[r].x, v[r].y * ww[r].y};
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int src = lsrc | wf_src_of_const<W>(wf_reg_part<W>(0, r));
+                const int k0 = (2 * src + hs) & (N - 1);
+                const int64_t g0 = a0 + k0;
+                const float x0 = g0 < a.ia.len ? in[(uint64_t)g0 & a.ia.mask] : 0.f;
+                const float x1 = g0 + 1 < a.ia.len ? in[(uint64_t)(g0 + 1) & a.ia.mask] : 0.f;
+                v[r] = cf{x0 * w[k0], x1 * w[k0 + 1]};
+            }
         }
     }
-    wf_fft_pass<W, 0, false>(v, lane, lds, tw);
+    constexpr int J = NC / 128;
+    const int lp0 = wf_lane_part<W>(0, lane), lp1 = wf_lane_part<W>(1, lane), lp2 = wf_lane_part<W>(2, lane);
+    wf_load_pass_tw<W, 1>(T1, lane, tw);
+    wf_apply_pass_stages<W, 0, false>(v, T0);
+    wf_store<W, 0>(lds, v, lp0);
     wave_sync();
-    wf_fft_pass<W, 1, false>(v, lane, lds, tw);
+    wf_load<W, 1>(lds, v, lp1);
+    wf_apply_pass_stages<W, 1, false>(v, T1);
+    wf_load_pass_tw<W, 2>(T2, lane, tw);
+    wf_store<W, 1>(lds, v, lp1);
     wave_sync();
-    wf_fft_pass<W, 2, false>(v, lane, lds, tw);
+    wf_load<W, 2>(lds, v, lp2);
+    wf_apply_pass_stages<W, 2, false>(v, T2);
+    cf sw[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) sw[j] = stw[lane + 64 * j];
+    const cf swmid = stw[NC / 2];
+    wf_store<W, 2>(lds, v, lp2);
     wave_sync();
 
     // real-FFT split (kiss_fftr.c:91-120) + polar (FFT.cc:2623-2630); lane handles k = lane + 64 j
     const int64_t plane = ((int64_t)row * a.TR + slot);
     float *__restrict__ mag = a.mag + plane * tb.HP;
     float *__restrict__ ph = a.phase + plane * tb.HP;
-    constexpr int J = NC / 128;
     float mlo[J], mhi[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
@@ -312,7 +362,7 @@ template <int NC> __global__ __launch_bounds__(256) void pv_analyze_wave_kernel(
             const cf fpnk = cf{q.x, -q.y};
             const cf f1k = wf_add(fpk, fpnk);
             const cf f2k = wf_sub(fpk, fpnk);
-            const cf tq = wf_cmul(f2k, stw[k]);
+            const cf tq = wf_cmul(f2k, sw[j]);
             const float xr = (f1k.x + tq.x) * 0.5f, xi = (f1k.y + tq.y) * 0.5f;
             const float yr = (f1k.x - tq.x) * 0.5f, yi = (tq.y - f1k.y) * 0.5f;
             mlo[j] = sqrtf(xr * xr + xi * xi);
@@ -329,7 +379,7 @@ template <int NC> __global__ __launch_bounds__(256) void pv_analyze_wave_kernel(
         const cf fpnk = cf{fpk.x, -fpk.y};
         const cf f1k = wf_add(fpk, fpnk);
         const cf f2k = wf_sub(fpk, fpnk);
-        const cf tq = wf_cmul(f2k, stw[NC / 2]);
+        const cf tq = wf_cmul(f2k, swmid);
         const float yr = (f1k.x - tq.x) * 0.5f, yi = (tq.y - f1k.y) * 0.5f;
         mmid = sqrtf(yr * yr + yi * yi);
         mag[NC / 2] = mmid;
@@ -591,11 +641,11 @@ __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *
             const uint32_t p1 = (r.p1r1 & 0xffffu) & (uint32_t)(hs - 1);
             // straight-line code (princarg_div has no rare-case branch): any branch inside this loop makes the
             // compiler fall back to vmcnt(0) at the joins, which exposes the store latency under load
-            const float po_lock = (float)princarg_div((double)(r.a1 + rprev[r1]));
+            const float po_lock = (float)princarg_small((double)(r.a1 + rprev[r1]));
             const float po_full = spo[p1];
             const float po = kind == 2 ? po_lock : (kind == 1 ? po_full : 0.f);
             const float tgt = (float)princarg_div((double)(po + r.adv));
-            const float rt = (float)princarg_div((double)(tgt - r.a2));
+            const float rt = (float)princarg_small((double)(tgt - r.a2));
             rcur[rix] = rt;
             a.rot[plane * a.PKP + rix] = rt;
             kind = 2;
@@ -618,11 +668,11 @@ __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *
             for (int p = tid; p < n; p += nt) {
                 const PeakRec r = a.recs[plane * a.PKP + p];
                 float po;
-                if (kind == 2) po = (float)princarg_div((double)(r.a1 + rprev[r.p1r1 >> 16]));
+                if (kind == 2) po = (float)princarg_small((double)(r.a1 + rprev[r.p1r1 >> 16]));
                 else if (kind == 1) po = spo[r.p1r1 & 0xffffu];
                 else po = 0.f;
                 const float tgt = (float)princarg_div((double)(po + r.adv));
-                const float rt = (float)princarg_div((double)(tgt - r.a2));
+                const float rt = (float)princarg_small((double)(tgt - r.a2));
                 rcur[p] = rt;
                 a.rot[plane * a.PKP + p] = rt;
             }
@@ -650,7 +700,7 @@ __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *
                     outv = phi;
                 } else {
                     float po;
-                    if (kind == 2) po = (float)princarg((double)(Ap[i] + rprev[region_of(spk, nsame, i)]));
+                    if (kind == 2) po = (float)princarg_small((double)(Ap[i] + rprev[region_of(spk, nsame, i)]));
                     else if (kind == 1) po = spo[i];
                     else po = 0.f;
                     const float pp = Ap ? Ap[i] : 0.f;
@@ -801,7 +851,7 @@ __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a
             __syncthreads();
             for (int k = threadIdx.x; k <= hs; k += nt) {
                 const float phi = A[k];
-                sph[k] = k < hs ? (float)princarg((double)(phi + srot[region_of(spk, n, k)])) : phi;
+                sph[k] = k < hs ? (float)princarg_small((double)(phi + srot[region_of(spk, n, k)])) : phi;
             }
         } else {
             const float *__restrict__ op = a.outphase + plane * tb.HP;
@@ -955,7 +1005,7 @@ template <int NC> __global__ __launch_bounds__(256) void pv_synth_wave_kernel(co
             for (int j = 0; j < JB; ++j) {
                 const int k = lane + 64 * j;
                 const int reg = pre[j] + __popcll(bits[j] & lemask);
-                sph[k] = (float)princarg((double)(A[k] + srot[reg]));
+                sph[k] = (float)princarg_small((double)(A[k] + srot[reg]));
             }
         } else {
             const float *__restrict__ op = a.outphase + plane * tb.HP;
@@ -1014,6 +1064,18 @@ template <int NC> __global__ __launch_bounds__(256) void pv_synth_wave_kernel(co
     // 3. kiss_fftri pre-pass (kiss_fftr.c:134-157): pairs (k, NC-k) into registers, then scattered into
     //    butterfly order.  k = lane + 64 j; NC - k = 64 * (JB - j - (lane != 0)) + ((64 - lane) & 63).
     constexpr int J = NC / 128;
+    constexpr bool kRoomy = NC <= 1024; // registers to spare for the earlier of two possible issue points
+    cf sw[J];
+    if (kRoomy) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) sw[j] = stw[lane + 64 * j];
+    }
+    const cf swmid = stw[NC / 2];
+    WfTw<W> T0, T1, T2;
+    if (kRoomy) {
+        wf_load_pass_tw<W, 0>(T0, lane, tw);
+        wf_load_pass_tw<W, 1>(T1, lane, tw);
+    }
     cf pa[J], pb[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
@@ -1034,7 +1096,7 @@ template <int NC> __global__ __launch_bounds__(256) void pv_synth_wave_kernel(co
             const cf fnkc = cf{pb[j].x, -pb[j].y};
             const cf fek = wf_add(fk, fnkc);
             const cf tq = wf_sub(fk, fnkc);
-            const cf fok = wf_cmul(tq, stw[lane + 64 * j]);
+            const cf fok = wf_cmul(tq, kRoomy ? sw[j] : stw[lane + 64 * j]);
             const cf u = wf_add(fek, fok);
             cf vv = wf_sub(fek, fok);
             vv.y = vv.y * -1.f;
@@ -1050,39 +1112,67 @@ template <int NC> __global__ __launch_bounds__(256) void pv_synth_wave_kernel(co
         const cf fnkc = cf{pmid.x, -pmid.y};
         const cf fek = wf_add(fk, fnkc);
         const cf tq = wf_sub(fk, fnkc);
-        const cf fok = wf_cmul(tq, stw[NC / 2]);
+        const cf fok = wf_cmul(tq, swmid);
         cf vv = wf_sub(fek, fok);
         vv.y = vv.y * -1.f;
         lds[W::pad(wf_e_of_src<W>(NC / 2))] = vv;
     }
     wave_sync();
 
-    // 4. inverse complex FFT
+    // 4. inverse complex FFT.  With registers to spare (N = 2048: 125 VGPRs, four waves per SIMD) the twiddles
+    //    are fetched a pass ahead and the synthesis window before the frame's first store (see the analysis
+    //    kernel); at N = 4096 the 32 values per lane leave no room for that and every load sits at its use.
     cf v[R];
     {
         const int lp = wf_lane_part<W>(0, lane);
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = lds[W::pad(lp | wf_reg_part<W>(0, r))];
     }
-    wave_sync();
-    wf_fft_pass<W, 0, true>(v, lane, lds, tw);
-    wave_sync();
-    wf_fft_pass<W, 1, true>(v, lane, lds, tw);
-    wave_sync();
-    wf_fft_pass<W, 2, true>(v, lane, lds, tw);
-    wave_sync();
-
-    // 5. ifftshift + synthesis window (phasevocoderimpl.h:183-198): two consecutive samples per lane
     const int fslot = (int)(t & (int64_t)(a.FR - 1));
     float *__restrict__ out = a.frames + ((int64_t)row * a.FR + fslot) * N;
     const float *__restrict__ w = tb.window;
+    if constexpr (kRoomy) {
+        const int lp0 = wf_lane_part<W>(0, lane), lp1 = wf_lane_part<W>(1, lane), lp2 = wf_lane_part<W>(2, lane);
+        wave_sync();
+        wf_apply_pass_stages<W, 0, true>(v, T0);
+        wf_store<W, 0>(lds, v, lp0);
+        wave_sync();
+        wf_load<W, 1>(lds, v, lp1);
+        wf_apply_pass_stages<W, 1, true>(v, T1);
+        wf_load_pass_tw<W, 2>(T2, lane, tw);
+        wf_store<W, 1>(lds, v, lp1);
+        wave_sync();
+        wf_load<W, 2>(lds, v, lp2);
+        wf_apply_pass_stages<W, 2, true>(v, T2);
+        float2 ww[NC / 64];
+#pragma unroll
+        for (int j = 0; j < NC / 64; ++j) ww[j] = *reinterpret_cast<const float2 *>(w + 2 * (lane + 64 * j));
+        wf_store<W, 2>(lds, v, lp2);
+        wave_sync();
+        // 5. ifftshift + synthesis window (phasevocoderimpl.h:183-198): two consecutive samples per lane
+#pragma unroll
+        for (int j = 0; j < NC / 64; ++j) {
+            const int i = 2 * (lane + 64 * j);        // output sample index (even)
+            const int e = ((i + hs) & (N - 1)) >> 1;  // complex element holding samples i+hs, i+hs+1
+            const cf z = lds[W::pad(e)];
+            *reinterpret_cast<float2 *>(out + i) = make_float2(z.x * ww[j].x, z.y * ww[j].y);
+        }
+    } else {
+        wave_sync();
+        wf_fft_pass<W, 0, true>(v, lane, lds, tw);
+        wave_sync();
+        wf_fft_pass<W, 1, true>(v, lane, lds, tw);
+        wave_sync();
+        wf_fft_pass<W, 2, true>(v, lane, lds, tw);
+        wave_sync();
 #pragma unroll 4
-    for (int j = 0; j < NC / 64; ++j) {
-        const int i = 2 * (lane + 64 * j);        // output sample index (even)
-        const int e = ((i + hs) & (N - 1)) >> 1;  // complex element holding samples i+hs, i+hs+1
-        const cf z = lds[W::pad(e)];
-        const float2 ww = *reinterpret_cast<const float2 *>(w + i);
-        *reinterpret_cast<float2 *>(out + i) = make_float2(z.x * ww.x, z.y * ww.y);
+        for (int j = 0; j < NC / 64; ++j) {
+            const int i = 2 * (lane + 64 * j);
+            const int e = ((i + hs) & (N - 1)) >> 1;
+            const cf z = lds[W::pad(e)];
+            const float2 ww = *reinterpret_cast<const float2 *>(w + i);
+            *reinterpret_cast<float2 *>(out + i) = make_float2(z.x * ww.x, z.y * ww.y);
+        }
     }
 }
 

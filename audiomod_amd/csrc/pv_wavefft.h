@@ -159,6 +159,62 @@ template <class W, int P, bool INV> PV_HD void wf_run_pass_stages(cf (&v)[W::R],
     if (W::NSTAGE > 5 && W::st_pass[5] == P) wf_stage<W, (W::NSTAGE > 5 ? 5 : 0), INV>(v, lp, tw);
 }
 
+// ---- the same stages with their twiddles fetched ahead of time ---------------------------------
+// A global load costs the wave a full memory round trip when it is issued right where its value is needed, so
+// the kernels issue a pass's twiddle loads one pass early (WfTw lives in registers; t[i][r] is the factor that
+// multiplies v[r] in the i-th stage of the pass, unused slots are never materialised).
+template <class W> struct WfTw {
+    cf t[3][W::R];
+};
+template <class W, int S> PV_HD void wf_stage_load_tw(cf (&t)[W::R], int lp, const cf *__restrict__ tw) {
+    constexpr int pass = W::st_pass[S], eb = W::st_bit[S], radix = W::st_radix[S];
+    constexpr int m = 1 << eb;
+    constexpr int fs = W::N_C / (m * radix);
+    constexpr int p = wf_find_regbit<W>(pass, eb);
+#pragma unroll
+    for (int r = 0; r < W::R; ++r) {
+        if ((r >> p) & (radix - 1)) continue;
+        const int k = (lp + wf_reg_part<W>(pass, r)) & (m - 1);
+        t[r + (1 << p)] = tw[k * fs];
+        if (radix == 4) {
+            t[r + (2 << p)] = tw[2 * k * fs];
+            t[r + (3 << p)] = tw[3 * k * fs];
+        }
+    }
+}
+template <class W, int S, bool INV> PV_HD void wf_stage_apply(cf (&v)[W::R], const cf (&t)[W::R]) {
+    constexpr int pass = W::st_pass[S], eb = W::st_bit[S], radix = W::st_radix[S];
+    constexpr int p = wf_find_regbit<W>(pass, eb);
+#pragma unroll
+    for (int r = 0; r < W::R; ++r) {
+        if ((r >> p) & (radix - 1)) continue;
+        if (radix == 4) {
+            wf_bfly4<INV>(v[r], v[r + (1 << p)], v[r + (2 << p)], v[r + (3 << p)], t[r + (1 << p)], t[r + (2 << p)],
+                          t[r + (3 << p)]);
+        } else {
+            wf_bfly2(v[r], v[r + (1 << p)], t[r + (1 << p)]);
+        }
+    }
+}
+template <class W, int P> constexpr int wf_first_stage() {
+    for (int s = 0; s < W::NSTAGE; ++s)
+        if (W::st_pass[s] == P) return s;
+    return 0;
+}
+template <class W, int P> PV_HD void wf_load_pass_tw(WfTw<W> &T, int lane, const cf *__restrict__ tw) {
+    const int lp = wf_lane_part<W>(P, lane);
+    constexpr int F = wf_first_stage<W, P>();
+    if constexpr (F + 0 < W::NSTAGE && W::st_pass[F + 0] == P) wf_stage_load_tw<W, F + 0>(T.t[0], lp, tw);
+    if constexpr (F + 1 < W::NSTAGE && W::st_pass[F + 1] == P) wf_stage_load_tw<W, F + 1>(T.t[1], lp, tw);
+    if constexpr (F + 2 < W::NSTAGE && W::st_pass[F + 2] == P) wf_stage_load_tw<W, F + 2>(T.t[2], lp, tw);
+}
+template <class W, int P, bool INV> PV_HD void wf_apply_pass_stages(cf (&v)[W::R], const WfTw<W> &T) {
+    constexpr int F = wf_first_stage<W, P>();
+    if constexpr (F + 0 < W::NSTAGE && W::st_pass[F + 0] == P) wf_stage_apply<W, F + 0, INV>(v, T.t[0]);
+    if constexpr (F + 1 < W::NSTAGE && W::st_pass[F + 1] == P) wf_stage_apply<W, F + 1, INV>(v, T.t[1]);
+    if constexpr (F + 2 < W::NSTAGE && W::st_pass[F + 2] == P) wf_stage_apply<W, F + 2, INV>(v, T.t[2]);
+}
+
 template <class W, int P> PV_HD void wf_store(cf *lds, const cf (&v)[W::R], int lp) {
 #pragma unroll
     for (int r = 0; r < W::R; ++r) lds[W::pad(lp | wf_reg_part<W>(P, r))] = v[r];
@@ -176,6 +232,14 @@ template <class W, int P, bool INV> PV_HD void wf_fft_pass(cf (&v)[W::R], int la
     const int lp = wf_lane_part<W>(P, lane);
     if (P > 0) wf_load<W, P>(lds, v, lp);
     wf_run_pass_stages<W, P, INV>(v, lp, tw);
+    wf_store<W, P>(lds, v, lp);
+}
+
+// The same pass with the twiddles already in registers (wf_load_pass_tw<W, P> issued earlier by the caller).
+template <class W, int P, bool INV> PV_HD void wf_fft_pass_tw(cf (&v)[W::R], int lane, cf *lds, const WfTw<W> &T) {
+    const int lp = wf_lane_part<W>(P, lane);
+    if (P > 0) wf_load<W, P>(lds, v, lp);
+    wf_apply_pass_stages<W, P, INV>(v, T);
     wf_store<W, P>(lds, v, lp);
 }
 

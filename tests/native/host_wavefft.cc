@@ -4,6 +4,7 @@
 // level-by-level butterflies over the same plan tables (which the oracle pins to the reference).
 // Build: g++ -O2 -std=c++17 -ffp-contract=off -Iinclude -Iaudiomod_amd/csrc tests/native/host_wavefft.cc \
 //            audiomod_amd/csrc/pv_plan.cc -o /tmp/host_wavefft
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -62,6 +63,32 @@ template <int NC, bool INV> static int check(unsigned seed) {
     }
     for (int lane = 0; lane < 64; ++lane) { cf v[W::R]; wf_fft_pass<W, 1, INV>(v, lane, lds.data(), tw.data()); }
     for (int lane = 0; lane < 64; ++lane) { cf v[W::R]; wf_fft_pass<W, 2, INV>(v, lane, lds.data(), tw.data()); }
+    for (int e = 0; e < NC; ++e) {
+        const cf g = lds[W::pad(e)];
+        if (memcmp(&g, &want[e], sizeof(cf)) != 0) ++bad;
+    }
+    // the same transform through the prefetched-twiddle entry points the kernels use
+    std::fill(lds.begin(), lds.end(), cf{0, 0});
+    for (int lane = 0; lane < 64; ++lane) {
+        cf v[W::R];
+        WfTw<W> T;
+        const int lp = wf_lane_part<W>(0, lane);
+        for (int r = 0; r < W::R; ++r) v[r] = in[wf_src_of<W>(lp | wf_reg_part<W>(0, r))];
+        wf_load_pass_tw<W, 0>(T, lane, tw.data());
+        wf_fft_pass_tw<W, 0, INV>(v, lane, lds.data(), T);
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+        cf v[W::R];
+        WfTw<W> T;
+        wf_load_pass_tw<W, 1>(T, lane, tw.data());
+        wf_fft_pass_tw<W, 1, INV>(v, lane, lds.data(), T);
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+        cf v[W::R];
+        WfTw<W> T;
+        wf_load_pass_tw<W, 2>(T, lane, tw.data());
+        wf_fft_pass_tw<W, 2, INV>(v, lane, lds.data(), T);
+    }
     for (int e = 0; e < NC; ++e) {
         const cf g = lds[W::pad(e)];
         if (memcmp(&g, &want[e], sizeof(cf)) != 0) ++bad;

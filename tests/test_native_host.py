@@ -1,0 +1,35 @@
+"""CPU checks of device-side arithmetic, compiled for the host from the same headers / the same text:
+the wave-FFT index math (audiomod_amd/csrc/pv_wavefft.h, both the in-place and the prefetched-twiddle entry
+points) and the divide-free princarg.  No GPU needed."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+
+
+def _build_and_run(tmp_path, sources, name):
+    exe = str(tmp_path / name)
+    cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", f"-I{ROOT}/include", f"-I{ROOT}/audiomod_amd/csrc"]
+    cmd += [os.path.join(ROOT, s) for s in sources] + ["-o", exe]
+    subprocess.run(cmd, check=True)
+    return subprocess.run([exe], capture_output=True, text=True)
+
+
+def test_wave_fft_bit_exact_on_host(tmp_path):
+    r = _build_and_run(tmp_path, ["tests/native/host_wavefft.cc", "audiomod_amd/csrc/pv_plan.cc"], "host_wavefft")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("bit-exact") == 4, r.stdout
+
+
+def test_princarg_small_matches_reference_expression(tmp_path):
+    r = _build_and_run(tmp_path, ["tests/native/host_princarg.cc"], "host_princarg")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 mismatches" in r.stdout, r.stdout
+    # the device function must be the same text as the one swept on the host
+    dev = open(os.path.join(ROOT, "audiomod_amd/csrc/pv_kernels.hip")).read()
+    for line in ("const double yn = x > 0.0 ? (x > Y ? 2.0 * Y : Y) : 0.0;", "return (x - yn) + PV_PI;"):
+        assert line in dev
