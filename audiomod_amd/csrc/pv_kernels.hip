@@ -256,7 +256,7 @@ __device__ __forceinline__ bool block_to_row_slice4(int Tn, int rows, int &row, 
     const int groups = (Tn + 3) >> 2;
     const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
     row = xcd + 8 * (q / groups);
-    tl = 4 * (q % groups) + (threadIdx.x >> 6);
+    tl = __builtin_amdgcn_readfirstlane(4 * (q % groups) + (threadIdx.x >> 6)); // wave-uniform: keep it scalar
     return row < rows && tl < Tn;
 }
 
@@ -949,76 +949,114 @@ template <int NC> __global__ __launch_bounds__(256) void pv_synth_wave_kernel(co
     uint16_t *spk = reinterpret_cast<uint16_t *>(srot + a.PKP);     // [PKP]
     constexpr int JB = NC / 64; // bins per lane (plus the Nyquist bin on lane 0)
 
-    // 1. output phase of every bin -> sph
+    // 1. every global value this frame needs, requested before anything is computed: the per-bin phases of
+    //    whichever source the mode selects, the magnitudes, and (phase-locked steps) the peak list and its
+    //    rotations, read speculatively up to the list's capacity so that they do not wait for the peak count.
     const int cslot = ring_slot(a.s0, tl, a.TR);
+    constexpr int QP = (NC / 3 + 9 + 63) / 64; // >= PKP / 64 (pv_engine.cc: pkmax = hs / 3 + 2)
+    const bool plain = !a.do_freq_comp && a.voc_band_len < 0; // magnitudes are used bin by bin, unmoved
+    const float *__restrict__ psrc = A;
+    int mode = kModeProp, n = 0;
+    bool zero_phase = false;
     if (a.voc_band_len >= 0) {
-        const float *__restrict__ cp = a.cphase + (int64_t)cslot * tb.HP;
-#pragma unroll
-        for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = cp[lane + 64 * j];
-        if (lane == 0) sph[hs] = cp[hs];
+        psrc = a.cphase + (int64_t)cslot * tb.HP;
     } else if (a.robotic) {
+        zero_phase = true;
+    } else if (a.passthru) {
+    } else if (a.whisper) {
+        psrc = a.whisper + ((int64_t)tl * a.C + row % a.C) * tb.HP;
+    } else if (a.coremode == 2) {
+    } else {
+        mode = a.coremode == 1 ? a.modes[plane] : kModeProp;
+        if (mode == kModeLock) n = a.npk[plane];
+        else psrc = a.outphase + plane * tb.HP;
+    }
+    float base[JB], mreg[JB];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) base[j] = psrc[lane + 64 * j];
+    // the Nyquist bin keeps its analysis phase in every mode but the carrier / whisper / robotic ones (:695-699)
+    float pnyq = (a.voc_band_len >= 0 || a.whisper) ? psrc[hs] : A[hs];
+    float mnyq = 0.f;
+    auto load_mags = [&]() { // issued once the peak list has left its registers (128-VGPR budget)
+        if (plain) { // the first half now, the second half while the first is being used (see below)
+#pragma unroll
+            for (int j = 0; j < JB / 2; ++j) mreg[j] = mag[lane + 64 * j];
+            mnyq = mag[hs];
+        }
+    };
+    uint16_t pkr[QP];
+    float rotr[QP];
+    if (mode == kModeLock) {
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+            const int i = lane + 64 * q;
+            const int ic = i < a.PKP ? i : 0;
+            pkr[q] = a.peaks[plane * a.PKP + ic];
+            rotr[q] = a.rot[plane * a.PKP + ic];
+        }
+    }
+
+    // 2. output phase of every bin -> sph
+    if (mode != kModeLock) load_mags();
+    if (zero_phase) {
 #pragma unroll
         for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = 0.f;
-        if (lane == 0) sph[hs] = 0.f;
-    } else if (a.passthru) {
-#pragma unroll
-        for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = A[lane + 64 * j];
-        if (lane == 0) sph[hs] = A[hs];
-    } else if (a.whisper) {
-        const float *__restrict__ wp = a.whisper + ((int64_t)tl * a.C + row % a.C) * tb.HP;
-#pragma unroll
-        for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = wp[lane + 64 * j];
-        if (lane == 0) sph[hs] = wp[hs];
-    } else if (a.coremode == 2) {
+        pnyq = 0.f;
+    } else if (a.coremode == 2 && !a.passthru && !a.whisper && a.voc_band_len < 0) {
         const float pinc_f = (float)a.phase_inc[tl], hop_f = (float)a.hop;
 #pragma unroll
-        for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = A[lane + 64 * j] * pinc_f / hop_f;
-        if (lane == 0) sph[hs] = A[hs];
-    } else {
-        const int mode = a.coremode == 1 ? a.modes[plane] : kModeProp;
-        if (mode == kModeLock) {
-            // region(k) = number of region boundaries <= k.  Boundaries go into a bitmap (one 64-bit word per
-            // 64 bins = per value of j), so the lookup is a prefix count + one masked popcount per bin.
-            const int n = a.npk[plane];
-            unsigned int *bits32 = reinterpret_cast<unsigned int *>(spk + a.PKP); // [2 * JB]
-            int *pre = reinterpret_cast<int *>(bits32 + 2 * JB);                  // [JB]
-            for (int i = lane; i < n; i += 64) {
-                spk[i] = a.peaks[plane * a.PKP + i];
-                srot[i] = a.rot[plane * a.PKP + i];
-            }
-            if (lane < 2 * JB) bits32[lane] = 0u;
-            wave_sync();
-            for (int i = lane; i + 1 < n; i += 64) {
-                const int b = ((int)spk[i] + (int)spk[i + 1] + 1) >> 1; // round(x.5) away from zero (:676-682)
-                atomicOr(&bits32[b >> 5], 1u << (b & 31));
-            }
-            wave_sync();
-            const unsigned long long *bits = reinterpret_cast<const unsigned long long *>(bits32);
-            if (lane < JB) {
-                int acc = 0;
-                for (int i = 0; i < lane; ++i) acc += __popcll(bits[i]);
-                pre[lane] = acc;
-            }
-            wave_sync();
-            const unsigned long long lemask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-#pragma unroll 4
-            for (int j = 0; j < JB; ++j) {
-                const int k = lane + 64 * j;
-                const int reg = pre[j] + __popcll(bits[j] & lemask);
-                sph[k] = (float)princarg_small((double)(A[k] + srot[reg]));
-            }
-        } else {
-            const float *__restrict__ op = a.outphase + plane * tb.HP;
+        for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = base[j] * pinc_f / hop_f;
+    } else if (mode == kModeLock) {
+        // region(k) = number of region boundaries <= k.  Boundaries go into a bitmap (one 64-bit word per
+        // 64 bins = per value of j), so the lookup is a prefix count + one masked popcount per bin.
+        unsigned int *bits32 = reinterpret_cast<unsigned int *>(spk + a.PKP); // [2 * JB]
+        int *pre = reinterpret_cast<int *>(bits32 + 2 * JB);                  // [JB]
 #pragma unroll
-            for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = op[lane + 64 * j];
+        for (int q = 0; q < QP; ++q) {
+            const int i = lane + 64 * q;
+            if (i < n) {
+                spk[i] = pkr[q];
+                srot[i] = rotr[q];
+            }
         }
-        if (lane == 0) sph[hs] = A[hs];
+        load_mags();
+        if (lane < 2 * JB) bits32[lane] = 0u;
+        wave_sync();
+        for (int i = lane; i + 1 < n; i += 64) {
+            const int b = ((int)spk[i] + (int)spk[i + 1] + 1) >> 1; // round(x.5) away from zero (:676-682)
+            atomicOr(&bits32[b >> 5], 1u << (b & 31));
+        }
+        wave_sync();
+        const unsigned long long *bits = reinterpret_cast<const unsigned long long *>(bits32);
+        if (lane < JB) {
+            int acc = 0;
+            for (int i = 0; i < lane; ++i) acc += __popcll(bits[i]);
+            pre[lane] = acc;
+        }
+        wave_sync();
+        const unsigned long long lemask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const int k = lane + 64 * j;
+            const int reg = pre[j] + __popcll(bits[j] & lemask);
+            sph[k] = (float)princarg_small((double)(base[j] + srot[reg]));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = base[j];
     }
+    if (lane == 0) sph[hs] = pnyq;
     wave_sync();
 
-    // 2. spectrum in registers: freqCompSlice gather (:869-916), gains, polar -> cartesian (FFT.cc:2711-2718)
+    // spectrum in registers: freqCompSlice gather (:869-916), gains, polar -> cartesian (FFT.cc:2711-2718)
     cf xs[JB];
     cf xnyq = cf{0.f, 0.f};
+    auto to_cartesian = [&](float mg, float p) -> cf {
+        mg *= a.inv_n;
+        float sn, cs;
+        sincosf(p, &sn, &cs);
+        return cf{mg * cs, mg * sn};
+    };
     auto spectrum_bin = [&](int k) -> cf {
         float mg, p;
         if (a.do_freq_comp) {
@@ -1040,21 +1078,24 @@ template <int NC> __global__ __launch_bounds__(256) void pv_synth_wave_kernel(co
                 p = sph[k];
             }
             mg *= a.fixed_gain;
-        } else if (a.voc_band_len >= 0) {
+        } else {
             mg = vocoder_mag(mag, a.cmag + (int64_t)cslot * tb.HP, k, hs, a.voc_band_len);
             p = sph[k];
-        } else {
-            mg = mag[k];
-            p = sph[k];
         }
-        mg *= a.inv_n;
-        float sn, cs;
-        sincosf(p, &sn, &cs);
-        return cf{mg * cs, mg * sn};
+        return to_cartesian(mg, p);
     };
+    if (plain) {
 #pragma unroll
-    for (int j = 0; j < JB; ++j) xs[j] = spectrum_bin(lane + 64 * j);
-    if (lane == 0) xnyq = spectrum_bin(hs);
+        for (int j = 0; j < JB; ++j) {
+            if (j < JB / 2) mreg[j + JB / 2] = mag[lane + 64 * (j + JB / 2)];
+            xs[j] = to_cartesian(mreg[j], sph[lane + 64 * j]);
+        }
+        if (lane == 0) xnyq = to_cartesian(mnyq, pnyq);
+    } else {
+#pragma unroll
+        for (int j = 0; j < JB; ++j) xs[j] = spectrum_bin(lane + 64 * j);
+        if (lane == 0) xnyq = spectrum_bin(hs);
+    }
     wave_sync();
 #pragma unroll
     for (int j = 0; j < JB; ++j) lds[lane + 64 * j] = xs[j];
