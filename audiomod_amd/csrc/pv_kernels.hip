@@ -252,22 +252,22 @@ __global__ __launch_bounds__(kFftThreads) void pv_analyze_kernel(const AnalyzeAr
 // analysis, wave-per-frame variant (N = 2048 / 4096): one 64-lane wave owns a slice, the four waves of a
 // workgroup take four consecutive slices of the same row.  No workgroup barrier anywhere.
 // --------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool block_to_row_slice4(int Tn, int rows, int &row, int &tl) {
-    const int groups = (Tn + 3) >> 2;
+template <int WPB> __device__ __forceinline__ bool block_to_row_slice_w(int Tn, int rows, int &row, int &tl) {
+    const int groups = (Tn + WPB - 1) / WPB;
     const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
     row = xcd + 8 * (q / groups);
-    tl = __builtin_amdgcn_readfirstlane(4 * (q % groups) + (threadIdx.x >> 6)); // wave-uniform: keep it scalar
+    tl = __builtin_amdgcn_readfirstlane(WPB * (q % groups) + (threadIdx.x >> 6)); // wave-uniform: keep it scalar
     return row < rows && tl < Tn;
 }
 
-template <int NC> __global__ __launch_bounds__(256) void pv_analyze_wave_kernel(const AnalyzeArgs a) {
+template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyze_wave_kernel(const AnalyzeArgs a) {
     using W = WF<NC>;
     constexpr int N = 2 * NC, hs = NC, R = W::R;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     cf *lds = reinterpret_cast<cf *>(smem_raw) + wave * W::LDS_CF;
     int row, tl;
-    if (!block_to_row_slice4(a.Tn, a.rows, row, tl)) return; // wave-uniform
+    if (!block_to_row_slice_w<WPB>(a.Tn, a.rows, row, tl)) return; // wave-uniform
     const DevTables &tb = a.tb;
     const int64_t t = a.t0 + tl;
     const int slot = ring_slot(a.s0, tl, a.TR);
@@ -402,17 +402,26 @@ template <int NC> __global__ __launch_bounds__(256) void pv_analyze_wave_kernel(
     }
     if (lane == 0) smag[NC / 2] = mmid;
     wave_sync();
-    uint16_t *__restrict__ pk = a.peaks + plane * a.PKP;
+    // ordered list first into LDS (behind the magnitudes), then out in whole 32-bit words: three coalesced
+    // stores per lane instead of one sparsely populated 16-bit store per group of 64 bins
+    uint16_t *slist = reinterpret_cast<uint16_t *>(smag + NC + 4); // [PKP], 16-byte aligned
     int running = 0;
-#pragma unroll 4
+#pragma unroll 8
     for (int g = 0; g < hs / 64; ++g) {
         const int b = lane + 64 * g;
         const bool isp = is_peak(smag, b, hs);
         const unsigned long long bm = __ballot(isp);
-        if (isp) pk[running + __popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)b;
+        if (isp) slist[running + __popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)b;
         running += __popcll(bm);
     }
-    if (lane == 0) a.npk[plane] = running;
+    if (lane == 0) {
+        a.npk[plane] = running;
+        if (running & 1) slist[running] = 0; // the odd tail shares a word with the last peak
+    }
+    wave_sync();
+    uint32_t *__restrict__ pk32 = reinterpret_cast<uint32_t *>(a.peaks + plane * a.PKP); // PKP % 8 == 0
+    const uint32_t *slist32 = reinterpret_cast<const uint32_t *>(slist);
+    for (int i = lane; 2 * i < running; i += 64) pk32[i] = slist32[i];
 }
 
 // kernels may need more than the default 64 KiB of dynamic LDS at the largest FFT sizes
@@ -425,15 +434,18 @@ template <typename K> static void allow_big_lds(K kernel, bool &done) {
 
 void launch_analyze(const AnalyzeArgs &a, hipStream_t st) {
     if (a.tb.nc == 1024 || a.tb.nc == 2048) {
-        const int grid4 = 8 * ((a.rows + 7) / 8) * ((a.Tn + 3) / 4);
         if (a.tb.nc == 1024) {
-            hipLaunchKernelGGL(pv_analyze_wave_kernel<1024>, dim3(grid4), dim3(256), 4 * WF<1024>::LDS_CF * sizeof(cf),
-                               st, a);
+            constexpr int WPB = 1; // one frame per workgroup: nothing couples the waves, and 8.6 KB of LDS each
+            const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
+            hipLaunchKernelGGL((pv_analyze_wave_kernel<1024, WPB>), dim3(grid), dim3(64 * WPB),
+                               WPB * WF<1024>::LDS_CF * sizeof(cf), st, a);
         } else {
+            constexpr int WPB = 4;
+            const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
             static bool big = false;
-            allow_big_lds(pv_analyze_wave_kernel<2048>, big);
-            hipLaunchKernelGGL(pv_analyze_wave_kernel<2048>, dim3(grid4), dim3(256), 4 * WF<2048>::LDS_CF * sizeof(cf),
-                               st, a);
+            allow_big_lds(pv_analyze_wave_kernel<2048, WPB>, big);
+            hipLaunchKernelGGL((pv_analyze_wave_kernel<2048, WPB>), dim3(grid), dim3(64 * WPB),
+                               WPB * WF<2048>::LDS_CF * sizeof(cf), st, a);
         }
         return;
     }
@@ -928,14 +940,14 @@ __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a
 // synthesis, wave-per-frame variant.  The wave-private LDS region is reused four times:
 // [output phases + rot/peak lists] -> [spectrum X] -> [butterfly-ordered input] -> [time-domain frame].
 // --------------------------------------------------------------------------------------------
-template <int NC> __global__ __launch_bounds__(256) void pv_synth_wave_kernel(const SynthArgs a) {
+template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_synth_wave_kernel(const SynthArgs a) {
     using W = WF<NC>;
     constexpr int N = 2 * NC, hs = NC, R = W::R;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     cf *lds = reinterpret_cast<cf *>(smem_raw) + wave * W::LDS_CF;
     int row, tl;
-    if (!block_to_row_slice4(a.Tn, a.rows, row, tl)) return; // wave-uniform
+    if (!block_to_row_slice_w<WPB>(a.Tn, a.rows, row, tl)) return; // wave-uniform
     const DevTables &tb = a.tb;
     const int64_t t = a.t0 + tl;
     const int64_t plane = (int64_t)row * a.TR + ring_slot(a.s0, tl, a.TR);
@@ -1185,18 +1197,20 @@ template <int NC> __global__ __launch_bounds__(256) void pv_synth_wave_kernel(co
         wave_sync();
         wf_load<W, 2>(lds, v, lp2);
         wf_apply_pass_stages<W, 2, true>(v, T2);
-        float2 ww[NC / 64];
+        float4 ww[NC / 128];
 #pragma unroll
-        for (int j = 0; j < NC / 64; ++j) ww[j] = *reinterpret_cast<const float2 *>(w + 2 * (lane + 64 * j));
+        for (int j = 0; j < NC / 128; ++j) ww[j] = *reinterpret_cast<const float4 *>(w + 4 * (lane + 64 * j));
         wf_store<W, 2>(lds, v, lp2);
         wave_sync();
-        // 5. ifftshift + synthesis window (phasevocoderimpl.h:183-198): two consecutive samples per lane
+        // 5. ifftshift + synthesis window (phasevocoderimpl.h:183-198): four consecutive samples per lane and
+        //    store (the stores are issue-bound: half as many 16-byte ones beat twice as many 8-byte ones)
 #pragma unroll
-        for (int j = 0; j < NC / 64; ++j) {
-            const int i = 2 * (lane + 64 * j);        // output sample index (even)
-            const int e = ((i + hs) & (N - 1)) >> 1;  // complex element holding samples i+hs, i+hs+1
-            const cf z = lds[W::pad(e)];
-            *reinterpret_cast<float2 *>(out + i) = make_float2(z.x * ww[j].x, z.y * ww[j].y);
+        for (int j = 0; j < NC / 128; ++j) {
+            const int i = 4 * (lane + 64 * j);        // output sample index
+            const int e = ((i + hs) & (N - 1)) >> 1;  // even: elements e, e+1 hold samples i+hs .. i+hs+3
+            const cf z0 = lds[W::pad(e)], z1 = lds[W::pad(e) + 1]; // same group of 16, so adjacent after padding
+            *reinterpret_cast<float4 *>(out + i) =
+                make_float4(z0.x * ww[j].x, z0.y * ww[j].y, z1.x * ww[j].z, z1.y * ww[j].w);
         }
     } else {
         wave_sync();
@@ -1219,17 +1233,20 @@ template <int NC> __global__ __launch_bounds__(256) void pv_synth_wave_kernel(co
 
 void launch_synth(const SynthArgs &a, hipStream_t st) {
     if (a.tb.nc == 1024 || a.tb.nc == 2048) {
-        const int grid4 = 8 * ((a.rows + 7) / 8) * ((a.Tn + 3) / 4);
         if (a.tb.nc == 1024) {
+            constexpr int WPB = 1;
+            const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
             static bool big1 = false;
-            allow_big_lds(pv_synth_wave_kernel<1024>, big1);
-            hipLaunchKernelGGL(pv_synth_wave_kernel<1024>, dim3(grid4), dim3(256), 4 * WF<1024>::LDS_CF * sizeof(cf),
-                               st, a);
+            allow_big_lds(pv_synth_wave_kernel<1024, WPB>, big1);
+            hipLaunchKernelGGL((pv_synth_wave_kernel<1024, WPB>), dim3(grid), dim3(64 * WPB),
+                               WPB * WF<1024>::LDS_CF * sizeof(cf), st, a);
         } else {
+            constexpr int WPB = 4;
+            const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
             static bool big2 = false;
-            allow_big_lds(pv_synth_wave_kernel<2048>, big2);
-            hipLaunchKernelGGL(pv_synth_wave_kernel<2048>, dim3(grid4), dim3(256), 4 * WF<2048>::LDS_CF * sizeof(cf),
-                               st, a);
+            allow_big_lds(pv_synth_wave_kernel<2048, WPB>, big2);
+            hipLaunchKernelGGL((pv_synth_wave_kernel<2048, WPB>), dim3(grid), dim3(64 * WPB),
+                               WPB * WF<2048>::LDS_CF * sizeof(cf), st, a);
         }
         return;
     }
