@@ -106,7 +106,7 @@ struct Core {
     DevTables tb{};
     DevBuf<int32_t> perm, iperm;
     DevBuf<float2> tw_fwd, tw_inv, st_fwd, st_inv;
-    DevBuf<float> window, sinc;
+    DevBuf<float> window, window_sh, sinc;
     DevBuf<float4> tab4;
     DevBuf<float> mag, phase, outphase, frames, rot;
     DevBuf<float> cmag, cphase; // vocoder: carrier planes [TR][HP]
@@ -197,6 +197,15 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     if ((st = up2(st_fwd, d.fft.st_fwd)) != PV_OK) return st;
     if ((st = up2(st_inv, d.fft.st_inv)) != PV_OK) return st;
     if ((st = window.upload(d.window)) != PV_OK) return st;
+    {
+        // the window delayed by d = 0..3 samples: a frame that starts d floats past a 16-byte boundary is read
+        // in aligned 16-byte pieces and multiplied by the copy that lines up with it (pv_analyze_wave_kernel)
+        const size_t pitch = (size_t)d.N + 8;
+        std::vector<float> sh(4 * pitch, 0.f);
+        for (int dd = 0; dd < 4; ++dd)
+            for (int j = 0; j < d.N; ++j) sh[dd * pitch + j + dd] = d.window[j];
+        if ((st = window_sh.upload(sh)) != PV_OK) return st;
+    }
     if ((st = sinc.upload(d.sinc)) != PV_OK) return st;
     {
         // interpolated-sinc coefficients expanded per sub-sample offset: row `off`, tap j = the four table
@@ -233,6 +242,7 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     tb.st_fwd = st_fwd.p;
     tb.st_inv = st_inv.p;
     tb.window = window.p;
+    tb.window_sh = window_sh.p;
 
     const int cm = d.cfg.coremode;
     const size_t planes = (size_t)rows * TR;

@@ -20,6 +20,7 @@ struct DevTables {
     const int32_t *iperm; // [nc] in -> out
     const float2 *tw_fwd, *tw_inv, *st_fwd, *st_inv;
     const float *window; // [N]
+    const float *window_sh; // [4][N + 8]: window_sh[d][j] = window[j - d] (0 outside), for 16-byte aligned frame loads
 };
 
 // Input addressing: sample `a` (absolute frame index of the stream) of stream s, channel c lives at

@@ -290,23 +290,44 @@ template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyz
         const int lp = wf_lane_part<W>(0, lane);
         const int lsrc = wf_src_of<W>(lp);
         const uint64_t m0 = (uint64_t)a0 & a.ia.mask;
-        if (a0 + N <= a.ia.len && ((m0 + (uint64_t)(N - 1)) & a.ia.mask) == m0 + (uint64_t)(N - 1)) {
-            // the whole frame lies inside the input and does not wrap the ring (wave-uniform, the common
-            // case): one base pointer, 32-bit lane offsets, no per-sample bounds checks
-            const float *__restrict__ fb = in + m0;
+        if (a0 + N + 4 <= a.ia.len && ((m0 + (uint64_t)(N + 3)) & a.ia.mask) == m0 + (uint64_t)(N + 3)) {
+            // The whole frame (and the 16 bytes after it) lies inside the input and does not wrap the ring
+            // (wave-uniform, the common case).  Aligned 16-byte loads of the span that contains the frame, times
+            // the window copy delayed by the frame's offset d into its first 16 bytes, staged through LDS: nine
+            // wide loads of each instead of 48 narrow permuted ones (the texture path is issue-bound), then the
+            // pass-0 layout is a pair of adjacent floats per register out of LDS.
+            const float *__restrict__ fp = in + m0;
+            const uintptr_t fa = reinterpret_cast<uintptr_t>(fp);
+            const int d = (int)((fa & 15u) >> 2);
+            const float4 *__restrict__ xb = reinterpret_cast<const float4 *>(fa & ~(uintptr_t)15);
+            const float4 *__restrict__ wb = reinterpret_cast<const float4 *>(tb.window_sh + (size_t)d * (N + 8));
+            constexpr int Q = N / 256; // 16-byte pieces per lane (plus one more on lane 0)
+            float4 xq[Q], wq[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                xq[q] = xb[lane + 64 * q];
+                wq[q] = wb[lane + 64 * q];
+            }
+            float4 xt = make_float4(0.f, 0.f, 0.f, 0.f), wt = xt;
+            if (lane == 0) {
+                xt = xb[64 * Q];
+                wt = wb[64 * Q];
+            }
+            float4 *stage4 = reinterpret_cast<float4 *>(lds);
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                stage4[lane + 64 * q] = make_float4(xq[q].x * wq[q].x, xq[q].y * wq[q].y, xq[q].z * wq[q].z, xq[q].w * wq[q].w);
+            if (lane == 0) stage4[64 * Q] = make_float4(xt.x * wt.x, xt.y * wt.y, xt.z * wt.z, xt.w * wt.w);
+            wave_sync();
+            const float *stage = reinterpret_cast<const float *>(lds) + d; // stage[k] = x[a0 + k] * w[k]
             const int kl = (2 * lsrc + hs) & (N - 1); // the register part only sets bits the lane part leaves clear
-            int kl1 = kl + 1;                // kept opaque: a0 may be odd, and a merged 8-byte load of an odd-aligned
-            asm volatile("" : "+v"(kl1));    // sample pair is slower than two 4-byte loads
-            float2 ww[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int kr = 2 * wf_src_of_const<W>(wf_reg_part<W>(0, r)); // < hs, disjoint from lsrc's bits
-                const int k0 = kl ^ kr;                                      // == (2 * (lsrc | src_r) + hs) & (N - 1)
-                ww[r] = *reinterpret_cast<const float2 *>(w + k0);
-                v[r] = cf{fb[k0], fb[kl1 ^ kr]};
+                const int kr = 2 * wf_src_of_const<W>(wf_reg_part<W>(0, r));
+                const int k0 = kl ^ kr; // == (2 * (lsrc | src_r) + hs) & (N - 1)
+                v[r] = cf{stage[k0], stage[k0 + 1]};
             }
-#pragma unroll
-            for (int r = 0; r < R; ++r) v[r] = cf{v[r].x * ww[r].x, v[r].y * ww[r].y};
+            wave_sync();
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -339,11 +360,11 @@ template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyz
     wf_store<W, 2>(lds, v, lp2);
     wave_sync();
 
-    // real-FFT split (kiss_fftr.c:91-120) + polar (FFT.cc:2623-2630); lane handles k = lane + 64 j
+    // real-FFT split (kiss_fftr.c:91-120) + polar (FFT.cc:2623-2630); lane handles k = lane + 64 j and NC - k
     const int64_t plane = ((int64_t)row * a.TR + slot);
     float *__restrict__ mag = a.mag + plane * tb.HP;
     float *__restrict__ ph = a.phase + plane * tb.HP;
-    float mlo[J], mhi[J];
+    float mlo[J], mhi[J], plo[J], phi[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int k = lane + 64 * j;
@@ -352,10 +373,8 @@ template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyz
             const float r0 = tdc.x + tdc.y, rn = tdc.x - tdc.y;
             mlo[0] = sqrtf(r0 * r0 + 0.f * 0.f);
             mhi[0] = sqrtf(rn * rn + 0.f * 0.f);
-            mag[0] = mlo[0];
-            ph[0] = atan2f(0.f, r0);
-            mag[NC] = mhi[0];
-            ph[NC] = atan2f(0.f, rn);
+            plo[0] = atan2f(0.f, r0);
+            phi[0] = atan2f(0.f, rn);
         } else {
             const cf fpk = lds[W::pad(k)];
             const cf q = lds[W::pad(NC - k)];
@@ -367,13 +386,11 @@ template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyz
             const float yr = (f1k.x - tq.x) * 0.5f, yi = (tq.y - f1k.y) * 0.5f;
             mlo[j] = sqrtf(xr * xr + xi * xi);
             mhi[j] = sqrtf(yr * yr + yi * yi);
-            mag[k] = mlo[j];
-            ph[k] = atan2f(xi, xr);
-            mag[NC - k] = mhi[j];
-            ph[NC - k] = atan2f(yi, yr);
+            plo[j] = atan2f(xi, xr);
+            phi[j] = atan2f(yi, yr);
         }
     }
-    float mmid = 0.f;
+    float mmid = 0.f, pmid = 0.f;
     if (lane == 0) { // k == NC/2 pairs with itself: the second assignment of the reference loop wins
         const cf fpk = lds[W::pad(NC / 2)];
         const cf fpnk = cf{fpk.x, -fpk.y};
@@ -382,26 +399,37 @@ template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyz
         const cf tq = wf_cmul(f2k, swmid);
         const float yr = (f1k.x - tq.x) * 0.5f, yi = (tq.y - f1k.y) * 0.5f;
         mmid = sqrtf(yr * yr + yi * yi);
-        mag[NC / 2] = mmid;
-        ph[NC / 2] = atan2f(yi, yr);
+        pmid = atan2f(yi, yr);
     }
-    if (!a.find_peaks) return;
-    wave_sync();
-    // magnitudes into the (now free) wave-private LDS region, then ordered peak compaction by ballots
+    // Out through the (now free) wave-private LDS region: a lane holds bins k and NC - k, the planes want runs of
+    // consecutive bins, and stores are issue-bound -- four 16-byte stores per lane and plane instead of sixteen
+    // 4-byte ones.  Phases first, magnitudes second: the magnitudes stay in LDS for the peak search.
     float *smag = reinterpret_cast<float *>(lds);
+    auto plane_out = [&](const float (&lo)[J], const float (&hi)[J], float mid, float *__restrict__ dst) {
+        wave_sync();
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const int k = lane + 64 * j;
-        if (j == 0 && lane == 0) {
-            smag[0] = mlo[0];
-            smag[NC] = mhi[0];
-        } else {
-            smag[k] = mlo[j];
-            smag[NC - k] = mhi[j];
+        for (int j = 0; j < J; ++j) {
+            const int k = lane + 64 * j;
+            if (j == 0 && lane == 0) {
+                smag[0] = lo[0];
+                smag[NC] = hi[0];
+            } else {
+                smag[k] = lo[j];
+                smag[NC - k] = hi[j];
+            }
         }
-    }
-    if (lane == 0) smag[NC / 2] = mmid;
-    wave_sync();
+        if (lane == 0) smag[NC / 2] = mid;
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < NC / 256; ++q) {
+            const int i4 = 4 * (lane + 64 * q);
+            *reinterpret_cast<float4 *>(dst + i4) = *reinterpret_cast<const float4 *>(smag + i4);
+        }
+        if (lane == 0) dst[NC] = hi[0];
+    };
+    plane_out(plo, phi, pmid, ph);
+    plane_out(mlo, mhi, mmid, mag);
+    if (!a.find_peaks) return;
     // ordered list first into LDS (behind the magnitudes), then out in whole 32-bit words: three coalesced
     // stores per lane instead of one sparsely populated 16-bit store per group of 64 bins
     uint16_t *slist = reinterpret_cast<uint16_t *>(smag + NC + 4); // [PKP], 16-byte aligned
