@@ -968,7 +968,10 @@ __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a
 // synthesis, wave-per-frame variant.  The wave-private LDS region is reused four times:
 // [output phases + rot/peak lists] -> [spectrum X] -> [butterfly-ordered input] -> [time-domain frame].
 // --------------------------------------------------------------------------------------------
-template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_synth_wave_kernel(const SynthArgs a) {
+// (N = 2048 is asked to fit four waves per SIMD, 128 VGPRs; the compiler gets there without spilling)
+template <int NC, int WPB>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(NC == 1024 ? 4 : 1))) void
+pv_synth_wave_kernel(const SynthArgs a) {
     using W = WF<NC>;
     constexpr int N = 2 * NC, hs = NC, R = W::R;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1011,16 +1014,19 @@ template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_synth_
         if (mode == kModeLock) n = a.npk[plane];
         else psrc = a.outphase + plane * tb.HP;
     }
-    float base[JB], mreg[JB];
+    // A lane owns runs of four consecutive bins, k = 4 (lane + 64 q) + c: one 16-byte load per run and plane
+    // (the texture path is issue-bound), and the spectrum goes to LDS as two 16-byte writes per run.
+    constexpr int QB = NC / 256; // runs per lane
+    float4 base[QB], mreg[QB];
 #pragma unroll
-    for (int j = 0; j < JB; ++j) base[j] = psrc[lane + 64 * j];
+    for (int q = 0; q < QB; ++q) base[q] = *reinterpret_cast<const float4 *>(psrc + 4 * (lane + 64 * q));
     // the Nyquist bin keeps its analysis phase in every mode but the carrier / whisper / robotic ones (:695-699)
     float pnyq = (a.voc_band_len >= 0 || a.whisper) ? psrc[hs] : A[hs];
     float mnyq = 0.f;
     auto load_mags = [&]() { // issued once the peak list has left its registers (128-VGPR budget)
         if (plain) { // the first half now, the second half while the first is being used (see below)
 #pragma unroll
-            for (int j = 0; j < JB / 2; ++j) mreg[j] = mag[lane + 64 * j];
+            for (int q = 0; q < QB / 2; ++q) mreg[q] = *reinterpret_cast<const float4 *>(mag + 4 * (lane + 64 * q));
             mnyq = mag[hs];
         }
     };
@@ -1036,19 +1042,21 @@ template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_synth_
         }
     }
 
-    // 2. output phase of every bin -> sph
+    // 2. output phase of every bin, in registers (and in sph for the modes that gather across bins)
     if (mode != kModeLock) load_mags();
     if (zero_phase) {
 #pragma unroll
-        for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = 0.f;
+        for (int q = 0; q < QB; ++q) base[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         pnyq = 0.f;
     } else if (a.coremode == 2 && !a.passthru && !a.whisper && a.voc_band_len < 0) {
         const float pinc_f = (float)a.phase_inc[tl], hop_f = (float)a.hop;
 #pragma unroll
-        for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = base[j] * pinc_f / hop_f;
+        for (int q = 0; q < QB; ++q)
+            base[q] = make_float4(base[q].x * pinc_f / hop_f, base[q].y * pinc_f / hop_f, base[q].z * pinc_f / hop_f,
+                                  base[q].w * pinc_f / hop_f);
     } else if (mode == kModeLock) {
         // region(k) = number of region boundaries <= k.  Boundaries go into a bitmap (one 64-bit word per
-        // 64 bins = per value of j), so the lookup is a prefix count + one masked popcount per bin.
+        // 64 bins), so the lookup is a prefix count + one masked popcount per bin.
         unsigned int *bits32 = reinterpret_cast<unsigned int *>(spk + a.PKP); // [2 * JB]
         int *pre = reinterpret_cast<int *>(bits32 + 2 * JB);                  // [JB]
 #pragma unroll
@@ -1074,22 +1082,30 @@ template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_synth_
             pre[lane] = acc;
         }
         wave_sync();
-        const unsigned long long lemask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+        const int b0 = 4 * (lane & 15); // bit of the run's first bin in its 64-bin word
 #pragma unroll
-        for (int j = 0; j < JB; ++j) {
-            const int k = lane + 64 * j;
-            const int reg = pre[j] + __popcll(bits[j] & lemask);
-            sph[k] = (float)princarg_small((double)(base[j] + srot[reg]));
+        for (int q = 0; q < QB; ++q) {
+            const int wd = (lane >> 4) + 4 * q; // == (4 (lane + 64 q)) >> 6
+            const unsigned long long word = bits[wd];
+            const int p0 = pre[wd];
+            auto rotated = [&](float ph, int c) -> float {
+                const int reg = p0 + __popcll(word & ((2ull << (b0 + c)) - 1ull));
+                return (float)princarg_small((double)(ph + srot[reg]));
+            };
+            base[q] = make_float4(rotated(base[q].x, 0), rotated(base[q].y, 1), rotated(base[q].z, 2),
+                                  rotated(base[q].w, 3));
         }
-    } else {
-#pragma unroll
-        for (int j = 0; j < JB; ++j) sph[lane + 64 * j] = base[j];
     }
-    if (lane == 0) sph[hs] = pnyq;
-    wave_sync();
+    if (!plain) {
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < QB; ++q) *reinterpret_cast<float4 *>(sph + 4 * (lane + 64 * q)) = base[q];
+        if (lane == 0) sph[hs] = pnyq;
+        wave_sync();
+    }
 
     // spectrum in registers: freqCompSlice gather (:869-916), gains, polar -> cartesian (FFT.cc:2711-2718)
-    cf xs[JB];
+    cf xs[QB][4];
     cf xnyq = cf{0.f, 0.f};
     auto to_cartesian = [&](float mg, float p) -> cf {
         mg *= a.inv_n;
@@ -1126,19 +1142,28 @@ template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_synth_
     };
     if (plain) {
 #pragma unroll
-        for (int j = 0; j < JB; ++j) {
-            if (j < JB / 2) mreg[j + JB / 2] = mag[lane + 64 * (j + JB / 2)];
-            xs[j] = to_cartesian(mreg[j], sph[lane + 64 * j]);
+        for (int q = 0; q < QB; ++q) {
+            if (q < QB / 2) mreg[q + QB / 2] = *reinterpret_cast<const float4 *>(mag + 4 * (lane + 64 * (q + QB / 2)));
+            xs[q][0] = to_cartesian(mreg[q].x, base[q].x);
+            xs[q][1] = to_cartesian(mreg[q].y, base[q].y);
+            xs[q][2] = to_cartesian(mreg[q].z, base[q].z);
+            xs[q][3] = to_cartesian(mreg[q].w, base[q].w);
         }
         if (lane == 0) xnyq = to_cartesian(mnyq, pnyq);
     } else {
 #pragma unroll
-        for (int j = 0; j < JB; ++j) xs[j] = spectrum_bin(lane + 64 * j);
+        for (int q = 0; q < QB; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xs[q][c] = spectrum_bin(4 * (lane + 64 * q) + c);
         if (lane == 0) xnyq = spectrum_bin(hs);
     }
     wave_sync();
 #pragma unroll
-    for (int j = 0; j < JB; ++j) lds[lane + 64 * j] = xs[j];
+    for (int q = 0; q < QB; ++q) {
+        float4 *dst = reinterpret_cast<float4 *>(lds + 4 * (lane + 64 * q));
+        dst[0] = make_float4(xs[q][0].x, xs[q][0].y, xs[q][1].x, xs[q][1].y);
+        dst[1] = make_float4(xs[q][2].x, xs[q][2].y, xs[q][3].x, xs[q][3].y);
+    }
     if (lane == 0) lds[hs] = xnyq;
     wave_sync();
 
