@@ -17,6 +17,7 @@
 
 #include "audiomod_pv.h"
 #include "pv_kernels.h"
+#include "pv_wavefft.h"
 #include "pv_plan.h"
 
 namespace pv {
@@ -106,6 +107,7 @@ struct Core {
     DevTables tb{};
     DevBuf<int32_t> perm, iperm;
     DevBuf<float2> tw_fwd, tw_inv, st_fwd, st_inv;
+    DevBuf<float4> twl_fwd, twl_inv;
     DevBuf<float> window, window_sh, sinc;
     DevBuf<float4> tab4;
     DevBuf<float> mag, phase, outphase, frames, rot;
@@ -195,6 +197,21 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     if ((st = up2(tw_fwd, d.fft.tw_fwd)) != PV_OK) return st;
     if ((st = up2(tw_inv, d.fft.tw_inv)) != PV_OK) return st;
     if ((st = up2(st_fwd, d.fft.st_fwd)) != PV_OK) return st;
+    if (d.fft.nc == 1024 || d.fft.nc == 2048) { // lane-major twiddle tables of the wave-per-frame kernels
+        auto lane_table = [&](const std::vector<cpx> &tw, DevBuf<float4> &dst) -> int {
+            std::vector<cf> twc(tw.size());
+            for (size_t i = 0; i < tw.size(); ++i) twc[i] = cf{tw[i].r, tw[i].i};
+            const int entries = d.fft.nc == 1024 ? wf_lane_table_entries<WF<1024>>() : wf_lane_table_entries<WF<2048>>();
+            std::vector<cf> out(2 * (size_t)entries * 64);
+            if (d.fft.nc == 1024) wf_build_lane_table<WF<1024>>(twc.data(), out.data());
+            else wf_build_lane_table<WF<2048>>(twc.data(), out.data());
+            std::vector<float4> o4((size_t)entries * 64);
+            for (size_t i = 0; i < o4.size(); ++i) o4[i] = make_float4(out[2 * i].x, out[2 * i].y, out[2 * i + 1].x, out[2 * i + 1].y);
+            return dst.upload(o4);
+        };
+        if ((st = lane_table(d.fft.tw_fwd, twl_fwd)) != PV_OK) return st;
+        if ((st = lane_table(d.fft.tw_inv, twl_inv)) != PV_OK) return st;
+    }
     if ((st = up2(st_inv, d.fft.st_inv)) != PV_OK) return st;
     if ((st = window.upload(d.window)) != PV_OK) return st;
     {
@@ -238,6 +255,8 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     tb.perm = perm.p;
     tb.iperm = iperm.p;
     tb.tw_fwd = tw_fwd.p;
+    tb.twl_fwd = twl_fwd.p;
+    tb.twl_inv = twl_inv.p;
     tb.tw_inv = tw_inv.p;
     tb.st_fwd = st_fwd.p;
     tb.st_inv = st_inv.p;

@@ -19,6 +19,7 @@ struct DevTables {
     const int32_t *perm;  // [nc] out -> in
     const int32_t *iperm; // [nc] in -> out
     const float2 *tw_fwd, *tw_inv, *st_fwd, *st_inv;
+    const float4 *twl_fwd, *twl_inv; // lane-major twiddles of the wave-FFT passes 1 and 2 (pv_wavefft.h), nc 1024 / 2048
     const float *window; // [N]
     const float *window_sh; // [4][N + 8]: window_sh[d][j] = window[j - d] (0 outside), for 16-byte aligned frame loads
 };

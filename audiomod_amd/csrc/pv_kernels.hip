@@ -276,6 +276,7 @@ template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyz
     const float *__restrict__ w = tb.window;
     const cf *__restrict__ tw = reinterpret_cast<const cf *>(tb.tw_fwd);
     const cf *__restrict__ stw = reinterpret_cast<const cf *>(tb.st_fwd);
+    const cf2 *__restrict__ twl = reinterpret_cast<const cf2 *>(tb.twl_fwd);
 
     // Every global load below is issued ahead of its use, as early as the 128-VGPR budget of four waves per SIMD
     // allows (a pass's twiddles while the previous pass finishes, the split's super-twiddles during the last pass,
@@ -301,22 +302,26 @@ template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyz
             const int d = (int)((fa & 15u) >> 2);
             const float4 *__restrict__ xb = reinterpret_cast<const float4 *>(fa & ~(uintptr_t)15);
             const float4 *__restrict__ wb = reinterpret_cast<const float4 *>(tb.window_sh + (size_t)d * (N + 8));
-            constexpr int Q = N / 256; // 16-byte pieces per lane (plus one more on lane 0)
-            float4 xq[Q], wq[Q];
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                xq[q] = xb[lane + 64 * q];
-                wq[q] = wb[lane + 64 * q];
-            }
+            constexpr int Q = N / 256; // 16-byte pieces per lane (plus one more on lane 0), eight at a time
+            float4 *stage4 = reinterpret_cast<float4 *>(lds);
             float4 xt = make_float4(0.f, 0.f, 0.f, 0.f), wt = xt;
             if (lane == 0) {
                 xt = xb[64 * Q];
                 wt = wb[64 * Q];
             }
-            float4 *stage4 = reinterpret_cast<float4 *>(lds);
 #pragma unroll
-            for (int q = 0; q < Q; ++q)
-                stage4[lane + 64 * q] = make_float4(xq[q].x * wq[q].x, xq[q].y * wq[q].y, xq[q].z * wq[q].z, xq[q].w * wq[q].w);
+            for (int q0 = 0; q0 < Q; q0 += 8) {
+                float4 xq[8], wq[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    xq[q] = xb[lane + 64 * (q0 + q)];
+                    wq[q] = wb[lane + 64 * (q0 + q)];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    stage4[lane + 64 * (q0 + q)] =
+                        make_float4(xq[q].x * wq[q].x, xq[q].y * wq[q].y, xq[q].z * wq[q].z, xq[q].w * wq[q].w);
+            }
             if (lane == 0) stage4[64 * Q] = make_float4(xt.x * wt.x, xt.y * wt.y, xt.z * wt.z, xt.w * wt.w);
             wave_sync();
             const float *stage = reinterpret_cast<const float *>(lds) + d; // stage[k] = x[a0 + k] * w[k]
@@ -342,16 +347,20 @@ template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyz
     }
     constexpr int J = NC / 128;
     const int lp0 = wf_lane_part<W>(0, lane), lp1 = wf_lane_part<W>(1, lane), lp2 = wf_lane_part<W>(2, lane);
-    wf_load_pass_tw<W, 1>(T1, lane, tw);
+    WfTwRaw<W, 1> raw1;
+    wf_fetch_pass_tw<W, 1>(raw1, lane, twl);
     wf_apply_pass_stages<W, 0, false>(v, T0);
     wf_store<W, 0>(lds, v, lp0);
     wave_sync();
     wf_load<W, 1>(lds, v, lp1);
+    wf_unpack_pass_tw<W, 1>(T1, raw1);
     wf_apply_pass_stages<W, 1, false>(v, T1);
-    wf_load_pass_tw<W, 2>(T2, lane, tw);
+    WfTwRaw<W, 2> raw2;
+    wf_fetch_pass_tw<W, 2>(raw2, lane, twl);
     wf_store<W, 1>(lds, v, lp1);
     wave_sync();
     wf_load<W, 2>(lds, v, lp2);
+    wf_unpack_pass_tw<W, 2>(T2, raw2);
     wf_apply_pass_stages<W, 2, false>(v, T2);
     cf sw[J];
 #pragma unroll
@@ -986,6 +995,7 @@ pv_synth_wave_kernel(const SynthArgs a) {
     const float *__restrict__ A = a.phase + plane * tb.HP;
     const cf *__restrict__ tw = reinterpret_cast<const cf *>(tb.tw_inv);
     const cf *__restrict__ stw = reinterpret_cast<const cf *>(tb.st_inv);
+    const cf2 *__restrict__ twl = reinterpret_cast<const cf2 *>(tb.twl_inv);
     const double Nd = (double)N;
     float *sph = reinterpret_cast<float *>(lds);                    // [hs + 1]
     float *srot = sph + hs + 4;                                     // [PKP]
@@ -1178,9 +1188,10 @@ pv_synth_wave_kernel(const SynthArgs a) {
     }
     const cf swmid = stw[NC / 2];
     WfTw<W> T0, T1, T2;
+    WfTwRaw<W, 1> raw1;
     if (kRoomy) {
         wf_load_pass_tw<W, 0>(T0, lane, tw);
-        wf_load_pass_tw<W, 1>(T1, lane, tw);
+        wf_fetch_pass_tw<W, 1>(raw1, lane, twl);
     }
     cf pa[J], pb[J];
 #pragma unroll
@@ -1244,11 +1255,14 @@ pv_synth_wave_kernel(const SynthArgs a) {
         wf_store<W, 0>(lds, v, lp0);
         wave_sync();
         wf_load<W, 1>(lds, v, lp1);
+        wf_unpack_pass_tw<W, 1>(T1, raw1);
         wf_apply_pass_stages<W, 1, true>(v, T1);
-        wf_load_pass_tw<W, 2>(T2, lane, tw);
+        WfTwRaw<W, 2> raw2;
+        wf_fetch_pass_tw<W, 2>(raw2, lane, twl);
         wf_store<W, 1>(lds, v, lp1);
         wave_sync();
         wf_load<W, 2>(lds, v, lp2);
+        wf_unpack_pass_tw<W, 2>(T2, raw2);
         wf_apply_pass_stages<W, 2, true>(v, T2);
         float4 ww[NC / 128];
 #pragma unroll

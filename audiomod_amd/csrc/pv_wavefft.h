@@ -18,6 +18,8 @@
 // the CPU, lane by lane, against the oracle.
 #pragma once
 
+#include <utility>
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define PV_HD __host__ __device__ __forceinline__
@@ -201,6 +203,106 @@ template <class W, int P> constexpr int wf_first_stage() {
         if (W::st_pass[s] == P) return s;
     return 0;
 }
+// ---- lane-major twiddle tables -------------------------------------------------------------------
+// A lane-dependent twiddle tw[q k fs], k = (lane part + register part) mod m, is a gather that touches up to
+// 48 cache lines per load instruction.  The host lays the values out once per (stage, butterfly, q) "slot" and
+// lane, two slots to a 16-byte entry, so that a pass fetches its twiddles with a few contiguous 16-byte loads:
+//   table[(wf_pass_base4<W, P>() + j) * 64 + lane] = { slot 2j of pass P, slot 2j + 1 }        (cf2, 16 bytes)
+// Butterflies of a stage whose k agree (k ignores the register bits above the stage's m) share their slots.
+template <class W> constexpr int wf_stage_first_reg(int s, int r) { // first butterfly of stage s with r's k
+    const int pass = W::st_pass[s], eb = W::st_bit[s], radix = W::st_radix[s], m = 1 << eb;
+    const int p = wf_find_regbit<W>(pass, eb);
+    const int rk = wf_reg_part<W>(pass, r) & (m - 1);
+    for (int r2 = 0; r2 < r; ++r2) {
+        if ((r2 >> p) & (radix - 1)) continue;
+        if ((wf_reg_part<W>(pass, r2) & (m - 1)) == rk) return r2;
+    }
+    return r;
+}
+// slot (within its pass) of factor q of the butterfly whose first register is r in stage s; slots_of_pass when
+// called with s == NSTAGE
+template <class W> constexpr int wf_slot_in_pass(int pass, int s_want, int r_want, int q) {
+    int slot = 0;
+    for (int s = 0; s < W::NSTAGE; ++s) {
+        if (W::st_pass[s] != pass) continue;
+        const int eb = W::st_bit[s], radix = W::st_radix[s];
+        const int p = wf_find_regbit<W>(pass, eb);
+        for (int r = 0; r < W::R; ++r) {
+            if ((r >> p) & (radix - 1)) continue;
+            const int first = wf_stage_first_reg<W>(s, r);
+            if (s == s_want && r == r_want) return first == r ? slot + (q - 1) : wf_slot_in_pass<W>(pass, s, first, q);
+            if (first == r) slot += radix - 1;
+        }
+    }
+    return slot;
+}
+template <class W> constexpr int wf_pass_slots(int pass) { return wf_slot_in_pass<W>(pass, W::NSTAGE, 0, 0); }
+template <class W> constexpr int wf_pass_entries(int pass) { return (wf_pass_slots<W>(pass) + 1) / 2; } // float4s
+template <class W, int P> constexpr int wf_pass_base4() { return P <= 1 ? 0 : wf_pass_entries<W>(1); }
+template <class W> constexpr int wf_lane_table_entries() { return wf_pass_entries<W>(1) + wf_pass_entries<W>(2); }
+
+// host: fill out[(entry * 64 + lane) * 2 + (slot & 1)] for passes 1 and 2 (out: 2 * entries * 64 values)
+template <class W> inline void wf_build_lane_table(const cf *tw, cf *out) {
+    for (int i = 0; i < 2 * wf_lane_table_entries<W>() * 64; ++i) out[i] = cf{0.f, 0.f};
+    for (int pass = 1; pass <= 2; ++pass) {
+        const int base4 = pass == 1 ? 0 : wf_pass_entries<W>(1);
+        for (int s = 0; s < W::NSTAGE; ++s) {
+            if (W::st_pass[s] != pass) continue;
+            const int eb = W::st_bit[s], radix = W::st_radix[s], m = 1 << eb;
+            const int fs = W::N_C / (m * radix);
+            const int p = wf_find_regbit<W>(pass, eb);
+            for (int r = 0; r < W::R; ++r) {
+                if ((r >> p) & (radix - 1)) continue;
+                if (wf_stage_first_reg<W>(s, r) != r) continue;
+                for (int q = 1; q < radix; ++q) {
+                    const int slot = wf_slot_in_pass<W>(pass, s, r, q);
+                    for (int lane = 0; lane < 64; ++lane) {
+                        int lp = 0;
+                        for (int i = 0; i < 6; ++i) lp |= ((lane >> i) & 1) << W::lanepos[pass][i];
+                        const int k = (lp + wf_reg_part<W>(pass, r)) & (m - 1);
+                        out[((base4 + slot / 2) * 64 + lane) * 2 + (slot & 1)] = tw[q * k * fs];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// the pass's entries (16 bytes each, contiguous across the wave), then the factors picked out of them
+struct alignas(16) cf2 {
+    cf a, b;
+};
+template <class W, int P> struct WfTwRaw {
+    cf2 e[wf_pass_entries<W>(P)];
+};
+template <class W, int P> PV_HD void wf_fetch_pass_tw(WfTwRaw<W, P> &raw, int lane, const cf2 *__restrict__ table) {
+    constexpr int NE = wf_pass_entries<W>(P), B4 = wf_pass_base4<W, P>();
+#pragma unroll
+    for (int j = 0; j < NE; ++j) raw.e[j] = table[(B4 + j) * 64 + lane];
+}
+// (register and factor indices are template parameters so that every slot number is a compile-time constant)
+template <class W, int P, int S, int RR, int Q> PV_HD void wf_unpack_one_tw(cf (&t)[W::R], const WfTwRaw<W, P> &raw) {
+    constexpr int eb = W::st_bit[S], radix = W::st_radix[S];
+    constexpr int p = wf_find_regbit<W>(P, eb);
+    if constexpr (((RR >> p) & (radix - 1)) == 0 && Q < radix) {
+        constexpr int slot = wf_slot_in_pass<W>(P, S, RR, Q);
+        t[RR + (Q << p)] = (slot & 1) ? raw.e[slot / 2].b : raw.e[slot / 2].a;
+    }
+}
+template <class W, int P, int S, int... I>
+PV_HD void wf_unpack_stage_seq(cf (&t)[W::R], const WfTwRaw<W, P> &raw, std::integer_sequence<int, I...>) {
+    (wf_unpack_one_tw<W, P, S, I / 3, 1 + I % 3>(t, raw), ...);
+}
+template <class W, int P, int S> PV_HD void wf_unpack_stage_tw(cf (&t)[W::R], const WfTwRaw<W, P> &raw) {
+    wf_unpack_stage_seq<W, P, S>(t, raw, std::make_integer_sequence<int, 3 * W::R>{});
+}
+template <class W, int P> PV_HD void wf_unpack_pass_tw(WfTw<W> &T, const WfTwRaw<W, P> &raw) {
+    constexpr int F = wf_first_stage<W, P>();
+    if constexpr (F + 0 < W::NSTAGE && W::st_pass[F + 0] == P) wf_unpack_stage_tw<W, P, F + 0>(T.t[0], raw);
+    if constexpr (F + 1 < W::NSTAGE && W::st_pass[F + 1] == P) wf_unpack_stage_tw<W, P, F + 1>(T.t[1], raw);
+    if constexpr (F + 2 < W::NSTAGE && W::st_pass[F + 2] == P) wf_unpack_stage_tw<W, P, F + 2>(T.t[2], raw);
+}
+
 template <class W, int P> PV_HD void wf_load_pass_tw(WfTw<W> &T, int lane, const cf *__restrict__ tw) {
     const int lp = wf_lane_part<W>(P, lane);
     constexpr int F = wf_first_stage<W, P>();

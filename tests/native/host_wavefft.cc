@@ -93,7 +93,41 @@ template <int NC, bool INV> static int check(unsigned seed) {
         const cf g = lds[W::pad(e)];
         if (memcmp(&g, &want[e], sizeof(cf)) != 0) ++bad;
     }
-    printf("NC %d inv %d: %s (%d mismatches)\n", NC, (int)INV, bad ? "FAIL" : "bit-exact", bad);
+    // and with passes 1 and 2 taking their twiddles from the lane-major table the engine uploads
+    std::vector<cf> table(2 * (size_t)wf_lane_table_entries<W>() * 64);
+    wf_build_lane_table<W>(tw.data(), table.data());
+    const cf2 *tab2 = reinterpret_cast<const cf2 *>(table.data());
+    std::fill(lds.begin(), lds.end(), cf{0, 0});
+    for (int lane = 0; lane < 64; ++lane) {
+        cf v[W::R];
+        WfTw<W> T;
+        const int lp = wf_lane_part<W>(0, lane);
+        for (int r = 0; r < W::R; ++r) v[r] = in[wf_src_of<W>(lp | wf_reg_part<W>(0, r))];
+        wf_load_pass_tw<W, 0>(T, lane, tw.data());
+        wf_fft_pass_tw<W, 0, INV>(v, lane, lds.data(), T);
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+        cf v[W::R];
+        WfTw<W> T;
+        WfTwRaw<W, 1> raw;
+        wf_fetch_pass_tw<W, 1>(raw, lane, tab2);
+        wf_unpack_pass_tw<W, 1>(T, raw);
+        wf_fft_pass_tw<W, 1, INV>(v, lane, lds.data(), T);
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+        cf v[W::R];
+        WfTw<W> T;
+        WfTwRaw<W, 2> raw;
+        wf_fetch_pass_tw<W, 2>(raw, lane, tab2);
+        wf_unpack_pass_tw<W, 2>(T, raw);
+        wf_fft_pass_tw<W, 2, INV>(v, lane, lds.data(), T);
+    }
+    for (int e = 0; e < NC; ++e) {
+        const cf g = lds[W::pad(e)];
+        if (memcmp(&g, &want[e], sizeof(cf)) != 0) ++bad;
+    }
+    printf("NC %d inv %d: %s (%d mismatches; lane table %d + %d slots)\n", NC, (int)INV, bad ? "FAIL" : "bit-exact", bad,
+           wf_pass_slots<W>(1), wf_pass_slots<W>(2));
     return bad != 0;
 }
 
