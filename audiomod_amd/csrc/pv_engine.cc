@@ -104,6 +104,7 @@ struct Core {
     int device = 0, S = 0, C = 0, rows = 0;
     int Tc = 0, TR = 0, FR = 0, HP = 0, pkmax = 0, PKP = 0, lookback = 0;
     int ola_lds_floats = 0;
+    int otab_off = 0, wacc_pitch = 0; // layout of one tile's row of host-planned values (pv_kernels.h OlaArgs)
     DevTables tb{};
     DevBuf<int32_t> perm, iperm;
     DevBuf<float2> tw_fwd, tw_inv, st_fwd, st_inv;
@@ -175,6 +176,8 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     const double step = d.resample ? (double)d.res_num / (double)d.res_den : 1.0;
     const int tile_span = (int)(kTileOut * step) + (d.resample ? d.filt_len : 0) + 4;
     ola_lds_floats = tile_span + 4;
+    otab_off = (ola_lds_floats + 3) & ~3;
+    wacc_pitch = otab_off + 2 * kTileOut;
     lookback = (d.N + tile_span) / d.min_shift + 3;
     if ((tile_span + d.N) / d.min_shift + 3 > kMaxTileFrames) {
         g_last_error = "hop too small relative to the FFT size for the OLA tile";
@@ -345,7 +348,7 @@ int Core::build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64
         // divides (channelinfo.cc:108 seeds [0] with 1; synthesiseSlice :1073 adds w[i] * float(area*1.5) per
         // frame, ascending t).  Float arithmetic, evaluated exactly as written (-ffp-contract=off).
         const size_t wbase = wacc.size();
-        wacc.resize(wbase + (size_t)ola_lds_floats, 1.0f);
+        wacc.resize(wbase + (size_t)wacc_pitch, 1.0f);
         for (int i = 0; i < tl.n_cnt; ++i) {
             const int64_t n = n_lo + i;
             float acc = n == 0 ? 1.f : 0.f;
@@ -354,6 +357,31 @@ int Core::build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64
                 if (off >= 0 && off < d.N) acc += d.window[(size_t)off] * d.win_gain;
             }
             wacc[wbase + (size_t)i] = acc;
+        }
+        // where each output of the tile sits in the OLA stream: last_sample = filt_len/2 + floor(k*num/den),
+        // samp_frac_num = (k*num) mod den (closed form of resample.c:548-554 from skip_zeros :1225), and from
+        // those the sub-sample offset and the interpolation fraction of resampler_basic_interpolate_single
+        // (:494-500, float arithmetic as written there).  Data-independent and the same for every row, so the
+        // 64-bit divisions happen here once instead of once per row in the kernel.
+        if (d.resample) {
+            uint32_t *ot = reinterpret_cast<uint32_t *>(wacc.data() + wbase + (size_t)otab_off);
+            for (int o = 0; o < tl.kcnt; ++o) {
+                const unsigned __int128 tot = (unsigned __int128)(k0 + o) * d.res_num;
+                const int64_t pos = (int64_t)(d.filt_len / 2) + (int64_t)(tot / d.res_den);
+                const uint32_t frac_num = (uint32_t)(tot % d.res_den);
+                const uint32_t xoff = (uint32_t)(pos - d.filt_len + 1 - n_lo);
+                uint32_t sub, fbits = 0;
+                if (d.interp) {
+                    const uint32_t ov = (uint32_t)d.oversample;
+                    sub = frac_num * ov / d.res_den;
+                    const float frac = ((float)((frac_num * ov) % d.res_den)) / d.res_den;
+                    memcpy(&fbits, &frac, 4);
+                } else {
+                    sub = frac_num;
+                }
+                ot[2 * o] = xoff | (sub << 16);
+                ot[2 * o + 1] = fbits;
+            }
         }
     }
     return PV_OK;
@@ -544,6 +572,8 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     oa.wacc = d_wacc;
     oa.sinc_len = d.resample ? (int)d.sinc.size() : 0;
     oa.lds_floats = ola_lds_floats;
+    oa.wacc_pitch = wacc_pitch;
+    oa.otab_off = otab_off;
     oa.tab_bytes = !d.resample ? 0
                    : d.interp  ? d.oversample * (d.filt_len + 1) * 16
                                : (int)((d.sinc.size() * sizeof(float) + 15) & ~(size_t)15);
@@ -848,7 +878,7 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
             b->ev_chunk.push_back((int)ci);
         }
         c.launch_chunk(ia, ch.t0, ch.Tn, b->d_pinc.p + ch.t0, b->d_tiles.p + ch.tile_begin, ch.ntiles, b->d_P.p,
-                       b->d_wacc.p + (size_t)ch.tile_begin * c.ola_lds_floats,
+                       b->d_wacc.p + (size_t)ch.tile_begin * c.wacc_pitch,
                        b->d_whisper.p ? b->d_whisper.p + (size_t)ch.t0 * c.C * c.HP : nullptr,
                        c.d.vocoder ? &car : nullptr, d_out, b->plan.out_frames, 0, st, ev,
                        fused ? &pending : nullptr, fused ? &next_pending : nullptr, b->chain_stream,

@@ -159,7 +159,10 @@ struct OlaArgs {
     const float *sinc;
     int sinc_len;
     const float4 *tab4; // interpolated mode: [oversample][filt_len + 1] expanded coefficient rows
-    const float *wacc;  // [ntiles][lds_floats] window-sum denominators of each tile's OLA samples
+    const float *wacc;  // [ntiles][wacc_pitch]: window-sum denominators of each tile's OLA samples, then (at
+                        // float offset otab_off) the tile's output table: per output two 32-bit words,
+                        // { x offset in the tile | sub-sample offset << 16, bits of the interpolation fraction }
+    int wacc_pitch, otab_off;
     int lds_floats; // capacity of the OLA tile in LDS
     int tab_bytes;  // LDS bytes of the resampler coefficient table (16-byte multiple)
     // output

@@ -1343,6 +1343,11 @@ __device__ __forceinline__ void ola_role(const OlaArgs &a, const int tile_i, con
     const OlaTile tile = a.tiles[tile_i];
     const int N = a.N, NF = a.filt_len;
 
+    // position of this thread's output in the tile, its sub-sample offset and interpolation fraction: planned
+    // on the host (pv_engine.cc build_tiles), one 8-byte entry per output, fetched ahead of the gather
+    const float *__restrict__ wacc = a.wacc + (int64_t)tile_i * a.wacc_pitch;
+    uint2 oe = make_uint2(0u, 0u);
+    if (a.resample && tid < tile.kcnt) oe = reinterpret_cast<const uint2 *>(wacc + a.otab_off)[tid];
     if (tid < tile.t_cnt) sP[tid] = (int)(a.P[tile.p_off + tid] - tile.n_lo);
     if (a.resample) {
         if (a.interp) {
@@ -1361,7 +1366,6 @@ __device__ __forceinline__ void ola_role(const OlaArgs &a, const int tile_i, con
     // contribute an exact +0.0f (adding +0 never changes a sum that started at +0), so the loads are
     // unconditional on a clamped address: no divergent branch, and the compiler can batch them.
     const float *__restrict__ fr = a.frames + (int64_t)row * a.FR * N;
-    const float *__restrict__ wacc = a.wacc + (int64_t)tile_i * a.lds_floats;
     for (int i = tid; i < tile.n_cnt; i += nt) {
         float acc = 0.f;
 #pragma unroll 4
@@ -1383,16 +1387,10 @@ __device__ __forceinline__ void ola_role(const OlaArgs &a, const int tile_i, con
         *out = ola[tid];
         return;
     }
-    // position of output k in the OLA stream: last_sample = filt_len/2 + floor(k*num/den),
-    // samp_frac_num = (k*num) mod den  (closed form of resample.c:548-554 from skip_zeros :1225)
-    const unsigned long long tot = (unsigned long long)k * a.num;
-    const int64_t pos = (int64_t)(NF / 2) + (int64_t)(tot / a.den);
-    const uint32_t frac_num = (uint32_t)(tot % a.den);
-    const float *x = ola + (int)(pos - NF + 1 - tile.n_lo); // tap j = 0
+    const float *x = ola + (int)(oe.x & 0xffffu); // tap j = 0
     if (a.interp) {
-        const uint32_t ov = (uint32_t)a.oversample;
-        const int offset = (int)(frac_num * ov / a.den);
-        const float frac = ((float)((frac_num * ov) % a.den)) / a.den;
+        const int offset = (int)(oe.x >> 16);
+        const float frac = __uint_as_float(oe.y);
         const float4 *__restrict__ T = tab4 + offset * (NF + 1);
         v2f a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll 8
@@ -1412,7 +1410,7 @@ __device__ __forceinline__ void ola_role(const OlaArgs &a, const int tile_i, con
         *out = (c0 * a01.x) + (c1 * a01.y) + (c2 * a23.x) + (c3 * a23.y);
     } else {
         float sum = 0.f;
-        const float *t = stab + frac_num * (uint32_t)NF;
+        const float *t = stab + (oe.x >> 16) * (uint32_t)NF;
         for (int j = 0; j < NF; ++j) sum += x[j] * t[j];
         *out = sum;
     }
