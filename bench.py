@@ -57,32 +57,85 @@ def make_input(torch, streams, frames, device, rank):
     return x
 
 
-def cpu_baseline(seconds=480):
+def cpu_baseline(seconds=480, all_cores_seconds=240):
     """The real reference (oracle/_ref/ref_driver, kind 'reference') or, where absent, the oracle port,
-    timed on ONE host core on one stereo stream of the same workload."""
+    timed on ONE host core on one stereo stream of the same workload (the reference is single-threaded);
+    then, as the fair whole-host figure, one independent stream per available core run side by side."""
     from audiomod_amd import signals
     from oracle import oracle_py as O
     frames = seconds * 48000
     x = np.tile(signals.voice(10 * 48000, 2), (1, (seconds + 9) // 10))[:, :frames]
     kw = dict(mode="normal_pitchshift", semitones=4.0, coremode=1, fftsize=2048)
+    res = {}
     if O.have_ref():
         kind = "reference"
         with tempfile.TemporaryDirectory() as d:
             fin = os.path.join(d, "in.f32")
             x.tofile(fin)
-            cmd = [O.REF_DRIVER, "offline", fin, os.path.join(d, "out.f32"), os.path.join(d, "cnt.txt"), "2",
-                   str(frames), "48000", "1.0", "4.0", "0", "1", "2048", "480", "1"]
+
+            def cmd(n_frames, tag):
+                return [O.REF_DRIVER, "offline", fin, os.path.join(d, f"out{tag}.f32"), os.path.join(d, f"cnt{tag}.txt"),
+                        "2", str(n_frames), "48000", "1.0", "4.0", "0", "1", "2048", "480", "1"]
             t0 = time.perf_counter()
-            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            subprocess.run(cmd(frames, ""), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             dt = time.perf_counter() - t0
+            ncpu = usable_cores()
+            if ncpu > 1:
+                fa = min(all_cores_seconds, seconds) * 48000
+                t0 = time.perf_counter()
+                ps = [subprocess.Popen(cmd(fa, i), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                      for i in range(ncpu)]
+                ok = all(p.wait() == 0 for p in ps)
+                dta = time.perf_counter() - t0
+                if ok:
+                    res["all_cores"] = {"cores": ncpu, "value": round(ncpu * fa * 2 / dta / 1e6, 3),
+                                        "x_realtime": round(ncpu * fa / 48000 / dta, 1),
+                                        "sample": f"{ncpu} independent stereo streams x {fa // 48000} s side by side, "
+                                                  f"wall {dta:.2f} s"}
     else:
         kind = "port"
         t0 = time.perf_counter()
         O.run_offline(x, **kw)
         dt = time.perf_counter() - t0
-    return {"value": round(frames * 2 / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": kind,
-            "x_realtime": round(seconds / dt, 2),
-            "sample": f"1 stereo stream x {seconds} s, same config, block 480, wall {dt:.2f} s"}
+    res.update({"value": round(frames * 2 / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": kind,
+                "x_realtime": round(seconds / dt, 2),
+                "sample": f"1 stereo stream x {seconds} s, same config, block 480, wall {dt:.2f} s"})
+    return res
+
+
+def usable_cores(cap=16):
+    """Cores this job may really use: the affinity mask, cut down by the cgroup CPU quota when there is one and
+    by `cap` (a one-GPU box's CPU share is 16 cores whatever the host has)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, cap))
+
+
+def copy_ceiling_gbps(torch, device, nbytes=1 << 30, reps=10):
+    """Device-to-device copy rate (bytes read + bytes written per second): the practical HBM ceiling next to
+    the 8 TB/s spec."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -91,7 +144,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=128, help="stereo streams per GPU (cfg5: 1024 / 8)")
-    ap.add_argument("--seconds", type=int, default=20, help="audio seconds per stream per step")
+    ap.add_argument("--seconds", type=int, default=60, help="audio seconds per stream per step (BASELINE.md: 60)")
     ap.add_argument("--coremode", type=int, default=1)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS),
                     help="BASELINE config to run (default cfg2 = configs[1], the one the metric is quoted on)")
@@ -203,6 +256,7 @@ def main():
         achieved = per_stage[dom_stage]["GBps"]
         traffic = traffic_db.get(dom) if (G == 1 and args.streams == 128 and args.config == "cfg2") else None
         pipeline_gbps = info["bytes_per_slice"] * slices_per_step_gpu * args.steps / dt / 1e9
+        copy_gbps = copy_ceiling_gbps(torch, device)
         line = {
             "metric": "Msamples/s (48 kHz stereo) phase-vocoder pitch-shift; x real-time per GPU",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -216,6 +270,7 @@ def main():
                        "parallelism": f"stream-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "copy_ceiling_GBps": round(copy_gbps, 1), "frac_of_copy_ceiling": round(achieved / copy_gbps, 4),
                          "stage": dom_stage, "slices_per_launch": round(slices_per_launch, 1),
                          "pipeline_GBps": round(pipeline_gbps, 1), "per_stage": per_stage,
                          "per_kernel": per_kernel},

@@ -15,8 +15,13 @@ import json
 import sys
 from collections import defaultdict
 
-NAMES = {"pv_analyze_wave_kernel<1024>": "pv_analyze_kernel", "pv_synth_wave_kernel<1024>": "pv_synth_kernel",
-         "pv_analyze_wave_kernel<2048>": "pv_analyze_kernel", "pv_synth_wave_kernel<2048>": "pv_synth_kernel"}
+def canonical(k):
+    """pv_analyze_wave_kernel<1024, 1> and friends are reported under the stage's kernel name"""
+    if k.startswith("pv_analyze_wave_kernel"):
+        return "pv_analyze_kernel"
+    if k.startswith("pv_synth_wave_kernel"):
+        return "pv_synth_kernel"
+    return k
 
 
 def main():
@@ -29,7 +34,7 @@ def main():
                 continue
             k = r["Kernel_Name"].split("(")[0].replace("pv::", "").replace("void ", "")
             if k.startswith("pv_"):
-                acc[NAMES.get(k, k)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                acc[canonical(k)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     res, detail = {}, {}
     for k, c in acc.items():
         # the first and last chunk of a run are shorter: use the median launch
