@@ -526,28 +526,59 @@ __device__ __forceinline__ int nearest_set_bit(const unsigned long long *bm, int
     return (up - p) < (p - dn) ? up : dn;
 }
 
+// LDS bytes of one wave (= one step) of the match kernel: two bitmaps + prefix counts, then three peak lists
+__host__ __device__ inline size_t match_wave_lds(int hs, int PKP) {
+    const int nw = (hs + 63) >> 6;
+    const size_t bm = (sizeof(unsigned long long) * 2 * nw + sizeof(int) * nw + 15) & ~(size_t)15;
+    return bm + 3 * (((size_t)PKP * sizeof(uint16_t) + 15) & ~(size_t)15);
+}
+
 __global__ __launch_bounds__(kMatchThreads) void pv_match_kernel(const MatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // bitmaps instead of sorted-list searches: "nearest previous peak" is a find-first-set around p2 in the
     // previous step's peak bitmap; "region of p1" is a prefix popcount over the boundary bitmap of the previous
-    // same-channel step (2-4 independent LDS reads instead of two 9-step dependent binary searches)
+    // same-channel step (2-4 independent LDS reads instead of two 9-step dependent binary searches).
+    // The wave's life is a chain of memory round trips, so there are three of them and no more: (1) the three
+    // peak counts and, speculatively and 16 bytes per lane, the three peak lists it may need; (2) the phases at
+    // the matched bins of up to six peaks per lane at once; (3) the records out.
     const int nw = (a.hs + 63) >> 6;
     const int wave = threadIdx.x >> 6;
-    char *wbase = smem_raw + (size_t)wave * (sizeof(unsigned long long) * 2 * nw + sizeof(int) * nw + 8);
+    char *wbase = smem_raw + (size_t)wave * match_wave_lds(a.hs, a.PKP);
     unsigned long long *bprev = reinterpret_cast<unsigned long long *>(wbase);    // [nw] peaks of the previous step
     unsigned long long *bbnd = bprev + nw;                                        // [nw] region boundaries, same channel
     int *pre = reinterpret_cast<int *>(bbnd + nw);                                // [nw] boundaries before each word
-    const int tl = blockIdx.x * 4 + wave, row = blockIdx.y, nt = 64, tid = threadIdx.x & 63;
+    const size_t lpitch = ((size_t)a.PKP * sizeof(uint16_t) + 15) & ~(size_t)15;
+    char *lbase = wbase + ((sizeof(unsigned long long) * 2 * nw + sizeof(int) * nw + 15) & ~(size_t)15);
+    uint16_t *lcur = reinterpret_cast<uint16_t *>(lbase);                         // [PKP] this step's peaks
+    uint16_t *lprev = reinterpret_cast<uint16_t *>(lbase + lpitch);               // [PKP] previous step's peaks
+    uint16_t *lsame = reinterpret_cast<uint16_t *>(lbase + 2 * lpitch);           // [PKP] previous same-channel step's
+    const int tl = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave), row = blockIdx.y, nt = 64;
+    const int tid = threadIdx.x & 63;
     if (tl >= a.Tn) return; // wave-uniform
     const int s = row / a.C, c = row - s * a.C;
     const int64_t t = a.t0 + tl;
     const int slot = ring_slot(a.s0, tl, a.TR), pslot = ring_prev(slot, a.TR);
     const int64_t plane = (int64_t)row * a.TR + slot;
-    const int ncur = a.npk[plane];
     int64_t pplane = -1; // plane of the previous step
     if (c > 0) pplane = (int64_t)(row - 1) * a.TR + slot;
     else if (t > 0) pplane = (int64_t)(s * a.C + a.C - 1) * a.TR + pslot;
+    const int64_t splane = t > 0 ? (int64_t)row * a.TR + pslot : -1;
+    // round trip 1
+    const int ncur = a.npk[plane];
     const int nprev = pplane >= 0 ? a.npk[pplane] : 0;
+    const int nsame = splane >= 0 ? a.npk[splane] : 0;
+    {
+        const uint4 *gcur = reinterpret_cast<const uint4 *>(a.peaks + plane * a.PKP);
+        const uint4 *gprev = reinterpret_cast<const uint4 *>(a.peaks + (pplane >= 0 ? pplane : plane) * a.PKP);
+        const uint4 *gsame = reinterpret_cast<const uint4 *>(a.peaks + (splane >= 0 ? splane : plane) * a.PKP);
+        const int n16 = a.PKP >> 3; // 16-byte pieces per list (PKP % 8 == 0)
+        for (int i = tid; i < n16; i += nt) {
+            const uint4 v0 = gcur[i], v1 = gprev[i], v2 = gsame[i];
+            reinterpret_cast<uint4 *>(lcur)[i] = v0;
+            reinterpret_cast<uint4 *>(lprev)[i] = v1;
+            reinterpret_cast<uint4 *>(lsame)[i] = v2;
+        }
+    }
     const bool first = (t == 0 && c == 0);
     const int mode = first ? kModeInit : ((ncur == 0 || nprev == 0) ? kModeProp : kModeLock);
     if (tid == 0) {
@@ -559,17 +590,15 @@ __global__ __launch_bounds__(kMatchThreads) void pv_match_kernel(const MatchArgs
         a.recs[plane * a.PKP + a.PKP - 1] = hdr;
     }
     if (mode != kModeLock) return;
-    const int64_t splane = t > 0 ? (int64_t)row * a.TR + pslot : -1;
-    const int nsame = splane >= 0 ? a.npk[splane] : 0;
     for (int i = tid; i < 2 * nw; i += nt) bprev[i] = 0ull; // bprev and bbnd are adjacent
     wave_sync();
     unsigned int *bprev32 = reinterpret_cast<unsigned int *>(bprev), *bbnd32 = reinterpret_cast<unsigned int *>(bbnd);
     for (int i = tid; i < nprev; i += nt) {
-        const int b = a.peaks[pplane * a.PKP + i];
+        const int b = lprev[i];
         atomicOr(&bprev32[b >> 5], 1u << (b & 31));
     }
     for (int i = tid; i + 1 < nsame; i += nt) {
-        const int b = ((int)a.peaks[splane * a.PKP + i] + (int)a.peaks[splane * a.PKP + i + 1] + 1) >> 1;
+        const int b = ((int)lsame[i] + (int)lsame[i + 1] + 1) >> 1;
         atomicOr(&bbnd32[b >> 5], 1u << (b & 31));
     }
     wave_sync();
@@ -580,35 +609,50 @@ __global__ __launch_bounds__(kMatchThreads) void pv_match_kernel(const MatchArgs
     }
     wave_sync();
     const float *__restrict__ A2 = a.phase + plane * a.HP;
-    const float *__restrict__ A1 = splane >= 0 ? a.phase + splane * a.HP : nullptr;
+    const float *__restrict__ A1 = a.phase + (splane >= 0 ? splane : plane) * a.HP;
     const float pinc_f = (float)a.phase_inc[tl], hop_f = (float)a.hop;
     const double Nd = (double)a.N;
-    for (int p = tid; p < ncur; p += nt) {
-        const int p2 = a.peaks[plane * a.PKP + p];
-        // nearest previous peak, ties -> lower bin (== the reference's monotone greedy walk :644-652)
-        const int p1 = nearest_set_bit(bprev, nw, p2);
-        const float avg_p = (float)((double)(p1 + p2) * 0.5);
-        const float pomega = (float)((a.two_pi_hop * (double)(avg_p - 1)) / Nd);
-        const float a2 = A2[p2];
-        const float a1 = A1 ? A1[p1] : 0.f; // prev_phase of this channel == its previous analysis phase
-        const float d1 = a2 - a1 - pomega;
-        const float pdelta = (float)((double)pomega + princarg((double)d1));
-        // region of p1 in the previous same-channel step = number of its boundaries <= p1
-        const int w1 = p1 >> 6, b1 = p1 & 63;
-        const unsigned long long le = b1 == 63 ? ~0ull : ((2ull << b1) - 1ull);
-        const int r1 = pre[w1] + __popcll(bbnd[w1] & le);
-        PeakRec r;
-        r.adv = (pdelta * pinc_f) / hop_f;
-        r.a2 = a2;
-        r.a1 = a1;
-        r.p1r1 = (uint32_t)p1 | ((uint32_t)r1 << 16);
-        a.recs[plane * a.PKP + p] = r;
+    constexpr int kU = 6; // peaks per lane whose phase gathers are in flight together (hs 1024: all of them)
+    for (int pb = 0; pb < ncur; pb += nt * kU) {
+        int p2v[kU], p1v[kU];
+        float a2v[kU], a1v[kU];
+        // round trip 2
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int p = pb + tid + nt * u;
+            p2v[u] = lcur[p < ncur ? p : ncur - 1];
+            // nearest previous peak, ties -> lower bin (== the reference's monotone greedy walk :644-652)
+            p1v[u] = nearest_set_bit(bprev, nw, p2v[u]);
+            a2v[u] = A2[p2v[u]];
+            a1v[u] = A1[p1v[u]]; // prev_phase of this channel == its previous analysis phase
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int p = pb + tid + nt * u;
+            if (p >= ncur) continue;
+            const int p2 = p2v[u], p1 = p1v[u];
+            const float avg_p = (float)((double)(p1 + p2) * 0.5);
+            const float pomega = (float)((a.two_pi_hop * (double)(avg_p - 1)) / Nd);
+            const float a2 = a2v[u];
+            const float a1 = splane >= 0 ? a1v[u] : 0.f;
+            const float d1 = a2 - a1 - pomega;
+            const float pdelta = (float)((double)pomega + princarg((double)d1));
+            // region of p1 in the previous same-channel step = number of its boundaries <= p1
+            const int w1 = p1 >> 6, b1 = p1 & 63;
+            const unsigned long long le = b1 == 63 ? ~0ull : ((2ull << b1) - 1ull);
+            const int r1 = pre[w1] + __popcll(bbnd[w1] & le);
+            PeakRec r;
+            r.adv = (pdelta * pinc_f) / hop_f;
+            r.a2 = a2;
+            r.a1 = a1;
+            r.p1r1 = (uint32_t)p1 | ((uint32_t)r1 << 16);
+            a.recs[plane * a.PKP + p] = r; // round trip 3
+        }
     }
 }
 
 void launch_match(const MatchArgs &a, hipStream_t st) {
-    const int nw = (a.hs + 63) >> 6;
-    const size_t lds = 4 * (sizeof(unsigned long long) * 2 * nw + sizeof(int) * nw + 8);
+    const size_t lds = 4 * match_wave_lds(a.hs, a.PKP);
     hipLaunchKernelGGL(pv_match_kernel, dim3((a.Tn + 3) / 4, a.rows), dim3(kMatchThreads), lds, st, a);
 }
 
