@@ -33,3 +33,19 @@ def test_princarg_small_matches_reference_expression(tmp_path):
     dev = open(os.path.join(ROOT, "audiomod_amd/csrc/pv_kernels.hip")).read()
     for line in ("const double yn = x > 0.0 ? (x > Y ? 2.0 * Y : Y) : 0.0;", "return (x - yn) + PV_PI;"):
         assert line in dev
+
+
+def test_host_planner_under_sanitizers(tmp_path):
+    """derive / Planner / plan_batch / carrier / whisper generators over ~900 configurations under ASan + UBSan"""
+    exe = str(tmp_path / "host_plan_sanitize")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-ffp-contract=off", f"-I{ROOT}/include", f"-I{ROOT}/audiomod_amd/csrc",
+           os.path.join(ROOT, "tests/native/host_plan_sanitize.cc"), os.path.join(ROOT, "audiomod_amd/csrc/pv_plan.cc"),
+           "-o", exe]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0 and ("asan" in b.stderr.lower() or "ubsan" in b.stderr.lower()):
+        pytest.skip("sanitizer runtimes not installed")
+    assert b.returncode == 0, b.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 failures" in r.stdout, r.stdout
