@@ -175,7 +175,7 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     // frames that can overlap one OLA tile / that must stay in the ring behind the newest slice
     const double step = d.resample ? (double)d.res_num / (double)d.res_den : 1.0;
     const int tile_span = (int)(kTileOut * step) + (d.resample ? d.filt_len : 0) + 4;
-    ola_lds_floats = tile_span + 4;
+    ola_lds_floats = (tile_span + 4 + 3) & ~3; // a multiple of 4: the gather writes the tile four samples at a time
     otab_off = (ola_lds_floats + 3) & ~3;
     wacc_pitch = otab_off + 2 * kTileOut;
     lookback = (d.N + tile_span) / d.min_shift + 3;

@@ -1393,16 +1393,15 @@ __device__ __forceinline__ void ola_role(const OlaArgs &a, const int tile_i, con
     uint2 oe = make_uint2(0u, 0u);
     if (a.resample && tid < tile.kcnt) oe = reinterpret_cast<const uint2 *>(wacc + a.otab_off)[tid];
     if (tid < tile.t_cnt) sP[tid] = (int)(a.P[tile.p_off + tid] - tile.n_lo);
-    if (a.resample) {
+    auto copy_table = [&](int first, int stride) {
+        if (!a.resample) return;
         if (a.interp) {
             const int cnt = a.oversample * (NF + 1);
-            for (int i = tid; i < cnt; i += nt) tab4[i] = a.tab4[i];
+            for (int i = first; i < cnt; i += stride) tab4[i] = a.tab4[i];
         } else {
-            for (int i = tid; i < a.sinc_len; i += nt) stab[i] = a.sinc[i];
+            for (int i = first; i < a.sinc_len; i += stride) stab[i] = a.sinc[i];
         }
-    }
-    __syncthreads();
-
+    };
     // y[n] = (sum_t frame_t[n - P_t]) / (delta[n] + sum_t gain*w[n - P_t]), ascending t, starting from 0.0f
     // (== outputAccumulator / windowAccumulator at the moment writeSlice divides them).  The denominator is
     // data-independent: the host planner evaluates it once per tile with the same float arithmetic
@@ -1410,17 +1409,89 @@ __device__ __forceinline__ void ola_role(const OlaArgs &a, const int tile_i, con
     // contribute an exact +0.0f (adding +0 never changes a sum that started at +0), so the loads are
     // unconditional on a clamped address: no divergent branch, and the compiler can batch them.
     const float *__restrict__ fr = a.frames + (int64_t)row * a.FR * N;
-    for (int i = tid; i < tile.n_cnt; i += nt) {
-        float acc = 0.f;
-#pragma unroll 4
-        for (int j = 0; j < tile.t_cnt; ++j) {
-            const int off = i - sP[j]; // n - P_t
-            const bool in = off >= 0 && off < N;
-            const int slot = (tile.t_first + j) & (a.FR - 1);
-            const float fv = fr[(int64_t)slot * N + (in ? off : 0)];
-            acc += in ? fv : 0.f;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool quads = nt == 256 && tile.n_cnt <= 4 * 126 && (N & 3) == 0;
+    if (!quads) copy_table(tid, nt);
+    __syncthreads();
+    if (quads) {
+        // The gather is the kernel's largest part and it is bound by the number of load instructions, so two
+        // waves fetch the frames 16 bytes per lane while the other two copy the coefficient table.  A lane owns
+        // four consecutive tile samples; a frame starts anywhere, so its samples for those four sit in two
+        // neighbouring aligned 16-byte pieces: the lane loads the lower one and takes the upper one from the
+        // next lane (DPP wave shift; lane 63 of a wave only serves as its lane 62's neighbour, so a wave covers
+        // 63 quads and the two waves 126).
+        if (wave < 2) {
+            const int u = 63 * wave + lane;
+            const float4 *__restrict__ fr4 = reinterpret_cast<const float4 *>(fr);
+            const int nq = N >> 2;
+            const float4 w4 = reinterpret_cast<const float4 *>(wacc)[4 * u < a.lds_floats ? u : 0];
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            constexpr int kF = 4; // frames whose loads are in flight together
+            for (int j0 = 0; j0 < tile.t_cnt; j0 += kF) {
+                float4 Av[kF];
+                int spv[kF];
+#pragma unroll
+                for (int q = 0; q < kF; ++q) {
+                    const int j = j0 + q < tile.t_cnt ? j0 + q : tile.t_cnt - 1;
+                    spv[q] = sP[j];
+                    const int f0 = 4 * u - spv[q]; // frame sample under the quad's first tile sample
+                    const int r = (-spv[q]) & 3;   // where in its aligned piece that sample sits (wave-uniform)
+                    const int qf = (f0 - r) >> 2;
+                    const int qc = qf < 0 ? 0 : (qf >= nq ? nq - 1 : qf);
+                    const int slot = (tile.t_first + j) & (a.FR - 1);
+                    Av[q] = fr4[(int64_t)slot * nq + qc];
+                }
+#pragma unroll
+                for (int q = 0; q < kF; ++q) {
+                    if (j0 + q >= tile.t_cnt) break; // wave-uniform
+                    const float4 A = Av[q];
+                    const int f0 = 4 * u - spv[q];
+                    const int r = (-spv[q]) & 3;
+                    float4 B;
+                    B.x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(A.x), 0x130, 0xf, 0xf, false));
+                    B.y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(A.y), 0x130, 0xf, 0xf, false));
+                    B.z = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(A.z), 0x130, 0xf, 0xf, false));
+                    float v0, v1, v2, v3;
+                    if (r == 0) {
+                        v0 = A.x, v1 = A.y, v2 = A.z, v3 = A.w;
+                    } else if (r == 1) {
+                        v0 = A.y, v1 = A.z, v2 = A.w, v3 = B.x;
+                    } else if (r == 2) {
+                        v0 = A.z, v1 = A.w, v2 = B.x, v3 = B.y;
+                    } else {
+                        v0 = A.w, v1 = B.x, v2 = B.y, v3 = B.z;
+                    }
+                    a0 += (f0 >= 0 && f0 < N) ? v0 : 0.f;
+                    a1 += (f0 + 1 >= 0 && f0 + 1 < N) ? v1 : 0.f;
+                    a2 += (f0 + 2 >= 0 && f0 + 2 < N) ? v2 : 0.f;
+                    a3 += (f0 + 3 >= 0 && f0 + 3 < N) ? v3 : 0.f;
+                }
+            }
+            if (lane < 63 && 4 * u < a.lds_floats) {
+                const int64_t n0 = tile.n_lo + 4 * u;
+                float4 y;
+                y.x = n0 >= 0 ? a0 / w4.x : 0.f;
+                y.y = n0 + 1 >= 0 ? a1 / w4.y : 0.f;
+                y.z = n0 + 2 >= 0 ? a2 / w4.z : 0.f;
+                y.w = n0 + 3 >= 0 ? a3 / w4.w : 0.f;
+                reinterpret_cast<float4 *>(ola)[u] = y;
+            }
+        } else {
+            copy_table(tid - 128, 128);
         }
-        ola[i] = tile.n_lo + i >= 0 ? acc / wacc[i] : 0.f;
+    } else {
+        for (int i = tid; i < tile.n_cnt; i += nt) {
+            float acc = 0.f;
+#pragma unroll 4
+            for (int j = 0; j < tile.t_cnt; ++j) {
+                const int off = i - sP[j]; // n - P_t
+                const bool in = off >= 0 && off < N;
+                const int slot = (tile.t_first + j) & (a.FR - 1);
+                const float fv = fr[(int64_t)slot * N + (in ? off : 0)];
+                acc += in ? fv : 0.f;
+            }
+            ola[i] = tile.n_lo + i >= 0 ? acc / wacc[i] : 0.f;
+        }
     }
     __syncthreads();
 
