@@ -737,7 +737,9 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
     *out = nullptr;
     std::unique_ptr<pv_batch> b(new pv_batch());
     const int rows = nstreams * cfg->channels;
-    int Tc = 16384 / (rows > 0 ? rows : 1);
+    // slices per launch and row: 64 K slices per launch amortise the launch's fixed costs and tail (measured:
+    // +8 % over 16 K with 256 rows; flat beyond), and the planes of such a chunk are a few GB of the 288
+    int Tc = 65536 / (rows > 0 ? rows : 1);
     if (Tc < 16) Tc = 16;
     if (Tc > 256) Tc = 256;
     if (const char *env = getenv("AUDIOMOD_PV_CHUNK_SLICES")) { // tuning knob: slices per launch and row
