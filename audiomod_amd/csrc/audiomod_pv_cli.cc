@@ -9,6 +9,7 @@
 //   audiomod-pv-exe normal_pitchshift  in.wav out.wav <semitones>  <coremode> <fftsize>
 //   audiomod-pv-exe formant_pitchshift in.wav out.wav <semitones>  <coremode> <fftsize>
 //   audiomod-pv-exe gender_change      in.wav out.wav <semitones>  <coremode> <fftsize>
+//   audiomod-pv-exe formant_cepstral   in.wav out.wav <semitones>  <coremode> <fftsize>   (extension of this engine)
 //   audiomod-pv-exe robotic | whisper | vocoder | vocoder_chord   in.wav out.wav
 //   audiomod-pv-exe constant           in.wav out.wav      (real-time processBlock loop, main.cc:561-572)
 // Effects of the reference that are not phase-vocoder modes are not provided here.
@@ -187,9 +188,13 @@ int main(int argc, char **argv) {
             if (argc < 7) { fprintf(stderr, "err: not enough para (time_ratio, coremode, fftsize)\n"); return -1; }
             pv.reset(new audiomod::phasevocoder(sr, ch, (float)atof(argv[4]), 0, NORMAL_STRETCH, atoi(argv[5]), atoi(argv[6])));
             flush = false; // the reference's time_stretch loop has no flush (main.cc:471-478)
-        } else if (model == "normal_pitchshift" || model == "formant_pitchshift" || model == "gender_change") {
+        } else if (model == "normal_pitchshift" || model == "formant_pitchshift" || model == "gender_change" ||
+                   model == "formant_cepstral") { // formant_cepstral: extension, see PV_MODE_FORMANT_CEPSTRAL
             if (argc < 7) { fprintf(stderr, "err: not enough para (pitchshift_amount, coremode, fftsize)\n"); return -1; }
-            const int mode = model == "normal_pitchshift" ? NORMAL_SHIFT : model == "formant_pitchshift" ? FORMANT_PRESERVE : GENDER_CHANGE;
+            const int mode = model == "normal_pitchshift"    ? NORMAL_SHIFT
+                             : model == "formant_pitchshift" ? FORMANT_PRESERVE
+                             : model == "formant_cepstral"   ? FORMANT_CEPSTRAL
+                                                             : GENDER_CHANGE;
             pv.reset(new audiomod::phasevocoder(sr, ch, 1, (float)atof(argv[4]), mode, atoi(argv[5]), atoi(argv[6])));
         } else if (model == "robotic" || model == "whisper" || model == "vocoder" || model == "vocoder_chord" ||
                    model == "constant") {

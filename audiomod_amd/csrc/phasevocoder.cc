@@ -17,7 +17,8 @@ static bool served_by_process_normal(int mode) {
     // per-slice work, reference phasevocoderimpl.cc:372-396)
     return mode == NORMAL_STRETCH || mode == NORMAL_SHIFT || mode == GENDER_CHANGE || mode == FORMANT_PRESERVE ||
            mode == ROBOTIC || mode == WHISPER || mode == CONSTANT || mode == VOCODER_ROSENBERG ||
-           mode == VOCODER_CHORD; // (the vocoder modes return the shaped carrier, retrieveCarrier)
+           mode == VOCODER_CHORD || // (the vocoder modes return the shaped carrier, retrieveCarrier)
+           mode == FORMANT_CEPSTRAL;
 }
 
 phasevocoder::phasevocoder(int sampleRate, int numChannels, float timeratio, float pitchshift, int mode,

@@ -549,6 +549,20 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     sa.rot = rot.p;
     sa.frames = frames.p;
     sa.FR = FR;
+    if (d.cepstral) {
+        CepstralArgs ca{};
+        ca.tb = tb;
+        ca.Tn = Tn;
+        ca.TR = TR;
+        ca.rows = rows;
+        ca.s0 = s0;
+        ca.env_comp = d.env_comp;
+        ca.inv_n = d.inv_n;
+        ca.mag = mag.p;
+        rec(2 * PV_K_CEPSTRAL);
+        launch_cepstral(ca, st);
+        rec(2 * PV_K_CEPSTRAL + 1);
+    }
     rec(2 * PV_K_SYNTH);
     launch_synth(sa, st);
     rec(2 * PV_K_SYNTH + 1);
@@ -696,7 +710,8 @@ int pv_device_count(void) { return count_gfx950(); }
 
 const char *pv_kernel_name(int k) {
     static const char *n[PV_NUM_KERNELS] = {"pv_analyze_kernel", "pv_match_kernel", "pv_seq_kernel",
-                                            "pv_prop_kernel",    "pv_synth_kernel", "pv_ola_kernel"};
+                                            "pv_prop_kernel",    "pv_synth_kernel", "pv_ola_kernel",
+                                            "pv_cepstral_kernel"};
     return (k >= 0 && k < PV_NUM_KERNELS) ? n[k] : "";
 }
 
@@ -903,6 +918,7 @@ int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launch
         for (int k = 0; k < PV_NUM_KERNELS; ++k) {
             if ((k == PV_K_MATCH || k == PV_K_SEQ) && cm != 1) continue;
             if (k == PV_K_PROP && cm != 0) continue;
+            if (k == PV_K_CEPSTRAL && !d.cepstral) continue;
             if (k == PV_K_OLA_RESAMPLE) {
                 // with the chain on its own stream the OLA events of chunk i bracket chunk i-1's overlap-add
                 const int ci2 = b->ev_chunk[i / kEvPerChunk] - (b->chain_stream ? 1 : 0);

@@ -135,6 +135,15 @@ struct SynthArgs {
 };
 
 // One workgroup of the OLA+resample kernel produces outputs [k0, k0+kcnt) of every (stream, channel).
+// cepstral formant shift of the magnitude planes (extension mode PV_MODE_FORMANT_CEPSTRAL)
+struct CepstralArgs {
+    DevTables tb;
+    int Tn, TR, rows, s0;
+    float env_comp; // the envelope is read at bin lrint(k * env_comp)
+    float inv_n;    // float(1.0 / N)
+    float *mag;     // [rows][TR][HP], modified in place
+};
+
 struct OlaTile {
     int64_t k0;      // first output index (resampled domain, or OLA domain when not resampling)
     int64_t n_lo;    // first OLA-stream sample the tile needs (may be negative: zero history)
@@ -176,6 +185,7 @@ void launch_match(const MatchArgs &a, hipStream_t st);
 void launch_seq(const SeqArgs &a, hipStream_t st);
 void launch_prop(const PropArgs &a, hipStream_t st);
 void launch_synth(const SynthArgs &a, hipStream_t st);
+void launch_cepstral(const CepstralArgs &a, hipStream_t st); // nc 1024 / 2048 only
 void launch_ola(const OlaArgs &a, hipStream_t st);
 
 } // namespace pv

@@ -1370,6 +1370,212 @@ void launch_synth(const SynthArgs &a, hipStream_t st) {
 }
 
 // --------------------------------------------------------------------------------------------
+// Cepstral formant shift of a slice's magnitudes (extension mode; the reference's formantShiftSlice,
+// phasevocoderprocess.cc:925-999, with D_KISSFFT::inverseCepstral FFT.cc:2723-2733 and ::forward :2606-2610 --
+// unreachable upstream, restated in oracle/pv_oracle.c formant_shift and pinned there on the real function):
+//   cep = kiss_fftri(log(mag + 1e-6));  keep the first 60 quefrencies (ends halved), times 1/N;
+//   envelope = exp(Re kiss_fftr(cep));  mag = mag / envelope * envelope[lrint(k * env_comp)]
+// One wave per (row, slice), both transforms through the wave-FFT core in the wave's LDS region.
+// --------------------------------------------------------------------------------------------
+template <int NC> __global__ __launch_bounds__(64) void pv_cepstral_wave_kernel(const CepstralArgs a) {
+    using W = WF<NC>;
+    constexpr int hs = NC, R = W::R, J = NC / 128, QB = NC / 256, kCut = 60;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    cf *lds = reinterpret_cast<cf *>(smem_raw);
+    int row, tl;
+    if (!block_to_row_slice_w<1>(a.Tn, a.rows, row, tl)) return; // wave-uniform
+    const DevTables &tb = a.tb;
+    const int64_t plane = (int64_t)row * a.TR + ring_slot(a.s0, tl, a.TR);
+    float *__restrict__ mag = a.mag + plane * tb.HP;
+    const cf *__restrict__ twi = reinterpret_cast<const cf *>(tb.tw_inv);
+    const cf *__restrict__ twf = reinterpret_cast<const cf *>(tb.tw_fwd);
+    const cf *__restrict__ sti = reinterpret_cast<const cf *>(tb.st_inv);
+    const cf *__restrict__ stf = reinterpret_cast<const cf *>(tb.st_fwd);
+
+    // magnitudes: runs of four consecutive bins per lane (kept in registers for the end), and the Nyquist bin
+    float4 m4[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) m4[q] = *reinterpret_cast<const float4 *>(mag + 4 * (lane + 64 * q));
+    const float mny = mag[hs];
+    // X[k] = (logf(mag[k] + 1e-6), 0) in natural order
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        float4 *dst = reinterpret_cast<float4 *>(lds + 4 * (lane + 64 * q));
+        dst[0] = make_float4(logf(m4[q].x + 0.000001f), 0.f, logf(m4[q].y + 0.000001f), 0.f);
+        dst[1] = make_float4(logf(m4[q].z + 0.000001f), 0.f, logf(m4[q].w + 0.000001f), 0.f);
+    }
+    const cf xnyq = cf{logf(mny + 0.000001f), 0.f};
+    wave_sync();
+
+    // kiss_fftri pre-pass (kiss_fftr.c:134-157), as in the synthesis kernel
+    cf v[R];
+    {
+        cf pa[J], pb[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int k = lane + 64 * j;
+            pa[j] = lds[k];
+            pb[j] = lds[(NC - k) & (NC - 1)];
+        }
+        if (lane == 0) pb[0] = xnyq;
+        const cf pmid = lds[NC / 2];
+        wave_sync();
+        const int e_lane = wf_e_of_src<W>(lane);
+        const int e_lane2 = wf_e_of_src<W>((64 - lane) & 63);
+        constexpr int JB = NC / 64;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (j == 0 && lane == 0) {
+                lds[W::pad(wf_e_of_src<W>(0))] = cf{pa[0].x + pb[0].x, pa[0].x - pb[0].x};
+            } else {
+                const cf fk = pa[j];
+                const cf fnkc = cf{pb[j].x, -pb[j].y};
+                const cf fek = wf_add(fk, fnkc);
+                const cf tq = wf_sub(fk, fnkc);
+                const cf fok = wf_cmul(tq, sti[lane + 64 * j]);
+                const cf u = wf_add(fek, fok);
+                cf vv = wf_sub(fek, fok);
+                vv.y = vv.y * -1.f;
+                const int e1 = e_lane | wf_e_of_src<W>(64 * j);
+                const int hi2 = lane != 0 ? wf_e_of_src<W>(64 * (JB - j - 1)) : wf_e_of_src<W>((64 * (JB - j)) & (NC - 1));
+                const int e2 = e_lane2 | hi2;
+                lds[W::pad(e1)] = u;
+                lds[W::pad(e2)] = vv;
+            }
+        }
+        if (lane == 0) {
+            const cf fk = pmid;
+            const cf fnkc = cf{pmid.x, -pmid.y};
+            const cf fek = wf_add(fk, fnkc);
+            const cf tq = wf_sub(fk, fnkc);
+            const cf fok = wf_cmul(tq, sti[NC / 2]);
+            cf vv = wf_sub(fek, fok);
+            vv.y = vv.y * -1.f;
+            lds[W::pad(wf_e_of_src<W>(NC / 2))] = vv;
+        }
+        wave_sync();
+        const int lp = wf_lane_part<W>(0, lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = lds[W::pad(lp | wf_reg_part<W>(0, r))];
+    }
+    wave_sync();
+    wf_fft_pass<W, 0, true>(v, lane, lds, twi);
+    wave_sync();
+    wf_fft_pass<W, 1, true>(v, lane, lds, twi);
+    wave_sync();
+    wf_fft_pass<W, 2, true>(v, lane, lds, twi);
+    wave_sync();
+
+    // lifter: element e of the transform holds cep[2e], cep[2e+1]; only the first 60 survive
+    cf z = cf{0.f, 0.f};
+    if (lane < kCut / 2) {
+        z = lds[W::pad(lane)];
+        if (lane == 0) z.x = z.x / 2;
+        if (lane == kCut / 2 - 1) z.y = z.y / 2;
+        z.x = z.x * a.inv_n;
+        z.y = z.y * a.inv_n;
+    }
+    wave_sync();
+    cf *zl = lds + W::LDS_CF - 32; // scratch at the end of the region (consumed before the next pass writes there)
+    if (lane < 32) zl[lane] = z;
+    wave_sync();
+    // forward transform of the zero-extended sequence: pass-0 layout straight from the 32 survivors
+    {
+        const int lp = wf_lane_part<W>(0, lane);
+        const int lsrc = wf_src_of<W>(lp);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int src = lsrc | wf_src_of_const<W>(wf_reg_part<W>(0, r));
+            const cf t = zl[src & 31];
+            v[r] = src < 32 ? t : cf{0.f, 0.f};
+        }
+    }
+    wave_sync();
+    wf_fft_pass<W, 0, false>(v, lane, lds, twf);
+    wave_sync();
+    wf_fft_pass<W, 1, false>(v, lane, lds, twf);
+    wave_sync();
+    wf_fft_pass<W, 2, false>(v, lane, lds, twf);
+    wave_sync();
+
+    // real parts of the real-FFT split (kiss_fftr.c:91-120), exponentiated: the spectral envelope
+    float elo[J], ehi[J], emid = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = lane + 64 * j;
+        if (j == 0 && lane == 0) {
+            const cf tdc = lds[W::pad(0)];
+            elo[0] = expf(tdc.x + tdc.y);
+            ehi[0] = expf(tdc.x - tdc.y);
+        } else {
+            const cf fpk = lds[W::pad(k)];
+            const cf q = lds[W::pad(NC - k)];
+            const cf fpnk = cf{q.x, -q.y};
+            const cf f1k = wf_add(fpk, fpnk);
+            const cf f2k = wf_sub(fpk, fpnk);
+            const cf tq = wf_cmul(f2k, stf[k]);
+            elo[j] = expf((f1k.x + tq.x) * 0.5f);
+            ehi[j] = expf((f1k.x - tq.x) * 0.5f);
+        }
+    }
+    if (lane == 0) {
+        const cf fpk = lds[W::pad(NC / 2)];
+        const cf fpnk = cf{fpk.x, -fpk.y};
+        const cf f1k = wf_add(fpk, fpnk);
+        const cf f2k = wf_sub(fpk, fpnk);
+        const cf tq = wf_cmul(f2k, stf[NC / 2]);
+        emid = expf((f1k.x - tq.x) * 0.5f);
+    }
+    wave_sync();
+    float *senv = reinterpret_cast<float *>(lds); // [hs + 1]
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = lane + 64 * j;
+        if (j == 0 && lane == 0) {
+            senv[0] = elo[0];
+            senv[NC] = ehi[0];
+        } else {
+            senv[k] = elo[j];
+            senv[NC - k] = ehi[j];
+        }
+    }
+    if (lane == 0) senv[NC / 2] = emid;
+    wave_sync();
+
+    // whiten by the envelope, re-colour by the envelope read at lrint(k * env_comp)
+    auto shifted = [&](int k) -> float {
+        if (a.env_comp > 1.0f) {
+            const int src = __float2int_rn((float)k * a.env_comp);
+            return src > hs ? 0.f : senv[src];
+        }
+        if (k == hs) return senv[hs]; // the downward loop of the reference never touches the Nyquist bin
+        return senv[__float2int_rn((float)k * a.env_comp)];
+    };
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        const int k0 = 4 * (lane + 64 * q);
+        const float4 e4 = *reinterpret_cast<const float4 *>(senv + k0);
+        float4 o;
+        o.x = (m4[q].x / e4.x) * shifted(k0);
+        o.y = (m4[q].y / e4.y) * shifted(k0 + 1);
+        o.z = (m4[q].z / e4.z) * shifted(k0 + 2);
+        o.w = (m4[q].w / e4.w) * shifted(k0 + 3);
+        *reinterpret_cast<float4 *>(mag + k0) = o;
+    }
+    if (lane == 0) mag[hs] = (mny / senv[hs]) * shifted(hs);
+}
+
+void launch_cepstral(const CepstralArgs &a, hipStream_t st) {
+    const int grid = 8 * ((a.rows + 7) / 8) * a.Tn;
+    if (a.tb.nc == 1024) {
+        hipLaunchKernelGGL((pv_cepstral_wave_kernel<1024>), dim3(grid), dim3(64), WF<1024>::LDS_CF * sizeof(cf), st, a);
+    } else {
+        hipLaunchKernelGGL((pv_cepstral_wave_kernel<2048>), dim3(grid), dim3(64), WF<2048>::LDS_CF * sizeof(cf), st, a);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // overlap-add + normalise + resample
 // --------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));

@@ -206,6 +206,7 @@ int derive(const pv_config &cfg, Derived &d) {
     case PV_MODE_CONSTANT:
     case PV_MODE_VOCODER_ROSENBERG:
     case PV_MODE_VOCODER_CHORD:
+    case PV_MODE_FORMANT_CEPSTRAL:
         break;
     default:
         return PV_ERR_UNSUPPORTED;
@@ -278,6 +279,14 @@ int derive(const pv_config &cfg, Derived &d) {
         d.freq_comp = (float)0.8;
     }
     d.fixed_gain = d.pitch_scale > 1 ? d.pitch_scale : 1 / d.pitch_scale;
+    // extension mode: formantShiftSlice(channel, m_pitchScale) where formantPreserveSlice has it commented out
+    if (cfg.mode == PV_MODE_FORMANT_CEPSTRAL) {
+        if (d.N != 2048 && d.N != 4096) return PV_ERR_UNSUPPORTED;
+        if (d.pitch_scale != 1.0) {
+            d.cepstral = true;
+            d.env_comp = d.pitch_scale;
+        }
+    }
 
     make_hann(d.N, d.window, d.win_area);
     d.win_gain = (float)(d.win_area * 1.5);

@@ -47,6 +47,8 @@ struct Derived {
     bool constant = false; // CONSTANT mode: no phase modification, out hop == in hop
     bool vocoder = false;  // channel vocoder: Rosenberg carrier shaped by the input's band magnitudes
     bool chord = false;    // VOCODER_CHORD: three-voice A-minor carrier
+    bool cepstral = false; // FORMANT_CEPSTRAL (extension): cepstral envelope shift by env_comp before synthesis
+    float env_comp = 1;
     int voc_band_len = 0;  // bins per band = floor(N / 1024) (modifySliceVocoder)
     bool do_freq_comp = false;
     float freq_comp = 1, fixed_gain = 1;

@@ -18,12 +18,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libaudiomod_pv.so")
 
 MODES = {"constant": -1, "normal_pitchshift": 0, "gender_change": 1, "formant_pitchshift": 2,
-         "vocoder": 3, "vocoder_chord": 4, "time_stretch": 5, "robotic": 6, "whisper": 7}
+         "vocoder": 3, "vocoder_chord": 4, "time_stretch": 5, "robotic": 6, "whisper": 7,
+         "formant_cepstral": 8}  # 8 = extension of this engine (PV_MODE_FORMANT_CEPSTRAL)
 CONSTANT, NORMAL_SHIFT, GENDER_CHANGE, FORMANT_PRESERVE = -1, 0, 1, 2
 VOCODER_ROSENBERG, VOCODER_CHORD, NORMAL_STRETCH, ROBOTIC, WHISPER = 3, 4, 5, 6, 7
+FORMANT_CEPSTRAL = 8
 NORMAL_PV, PHASE_LOCKED, INT_RATIO = 0, 1, 2
 KERNELS = ("pv_analyze_kernel", "pv_match_kernel", "pv_seq_kernel", "pv_prop_kernel", "pv_synth_kernel",
-           "pv_ola_kernel")
+           "pv_ola_kernel", "pv_cepstral_kernel")
 
 
 class PvError(RuntimeError):

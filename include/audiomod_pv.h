@@ -33,6 +33,11 @@ extern "C" {
 #define PV_MODE_NORMAL_STRETCH 5
 #define PV_MODE_ROBOTIC 6
 #define PV_MODE_WHISPER 7
+/* Extension, not a value of the reference's enum: pitch shift whose formants are restored by the reference's
+ * cepstral formant shift (formantShiftSlice, phasevocoderprocess.cc:925-999, with env_comp = the pitch scale) --
+ * code the reference carries but never calls (its call in formantPreserveSlice is commented out, :838).
+ * fftsize 2048 or 4096 only. */
+#define PV_MODE_FORMANT_CEPSTRAL 8
 #define PV_CORE_NORMAL_PV 0
 #define PV_CORE_PHASE_LOCKED 1
 #define PV_CORE_INT_RATIO 2
@@ -136,13 +141,14 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
  * record costs stream time, so full instrumentation slows the run by about 10 %).  After synchronising the
  * stream, pv_batch_kernel_times returns, for each of PV_NUM_KERNELS kernels, the summed device time in ms and
  * the number of instrumented launches since timing was enabled, and resets the accumulation window. */
-#define PV_NUM_KERNELS 6
+#define PV_NUM_KERNELS 7
 #define PV_K_ANALYZE 0      /* window + forward real FFT + polar (+ peak picking) */
 #define PV_K_MATCH 1        /* phase-locked: peak matching, parallel part */
 #define PV_K_SEQ 2          /* phase-locked: per-peak rotation chain, sequential over slices */
 #define PV_K_PROP 3         /* coremode 0: per-bin phase recurrence */
 #define PV_K_SYNTH 4        /* phase application + freqComp + inverse real FFT + window */
 #define PV_K_OLA_RESAMPLE 5 /* overlap-add + normalise + resample */
+#define PV_K_CEPSTRAL 6     /* PV_MODE_FORMANT_CEPSTRAL: cepstral envelope shift of the magnitudes */
 int pv_batch_enable_timing(pv_batch *b, int on);
 int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launches[PV_NUM_KERNELS]);
 const char *pv_kernel_name(int k);

@@ -19,6 +19,9 @@
 #define NORMAL_STRETCH 5
 #define ROBOTIC 6
 #define WHISPER 7
+// extension of this engine (not a reference mode): pitch shift with cepstral formant restoration, see
+// PV_MODE_FORMANT_CEPSTRAL in audiomod_pv.h
+#define FORMANT_CEPSTRAL 8
 // coremode
 #define NORMAL_PV 0
 #define PHASE_LOCKED 1

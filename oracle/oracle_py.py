@@ -17,7 +17,8 @@ REF_DRIVER = os.path.join(REF_DIR, "ref_driver")
 REF_KAT = os.path.join(REF_DIR, "ref_kat")
 
 MODES = {"constant": -1, "normal_pitchshift": 0, "gender_change": 1, "formant_pitchshift": 2,
-         "vocoder": 3, "vocoder_chord": 4, "time_stretch": 5, "robotic": 6, "whisper": 7}
+         "vocoder": 3, "vocoder_chord": 4, "time_stretch": 5, "robotic": 6, "whisper": 7,
+         "formant_cepstral": 8}  # 8: extension, the reference's unreachable cepstral formant shift
 
 
 class Config(C.Structure):
@@ -60,6 +61,7 @@ def lib():
         L.pvo_hann.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.pvo_forward_polar.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pvo_inverse_polar.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pvo_formant_shift.argtypes = [C.c_int, C.c_void_p, C.c_float]
         L.pvo_princarg.restype = C.c_double
         L.pvo_princarg.argtypes = [C.c_double]
         L.pvo_res_create.restype = C.c_void_p

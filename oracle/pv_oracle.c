@@ -619,7 +619,8 @@ struct pvo {
     chan *car;        /* carrier channelinfo per channel (vocoder modes) */
     rsb *gen;         /* [channels] single-voice generators */
     rsb *chord;       /* [channels][3] */
-    int opt_gender, opt_formant, opt_robotic, opt_whisper;
+    int opt_gender, opt_formant, opt_robotic, opt_whisper, opt_cepstral;
+    float *cep, *cenv; /* scratch of the cepstral formant shift */
     float time_ratio, pitch_scale;
     size_t N, hop, outbuf_size;
     int hop_out_nominal;
@@ -661,6 +662,7 @@ pvo *pvo_create(const pvo_config *cfg) {
     h->opt_formant = cfg->mode == PVO_FORMANT_PRESERVE;
     h->opt_robotic = cfg->mode == PVO_ROBOTIC;
     h->opt_whisper = cfg->mode == PVO_WHISPER;
+    h->opt_cepstral = cfg->mode == PVO_FORMANT_CEPSTRAL;
 
     /* calculateSizes, phasevocoderimpl.cc:169-263 */
     size_t windowSize = nextpow2((size_t)cfg->fftsize);
@@ -752,6 +754,8 @@ pvo *pvo_create(const pvo_config *cfg) {
 
 void pvo_destroy(pvo *h) {
     if (!h) return;
+    free(h->cep);
+    free(h->cenv);
     for (int c = 0; c < h->cfg.channels; ++c) {
         chan *a = &h->ch[c];
         ring_free(&a->inbuf); ring_free(&a->outbuf);
@@ -924,10 +928,65 @@ static void freq_comp(pvo *h, chan *a, float freq_comp) {
     for (int i = 0; i < hs + 1; ++i) mag[i] *= fixedgain;
 }
 
+/* Cepstral formant shift: phasevocoderprocess.cc:925-999 (formantShiftSlice) with FFT.cc:2723-2733
+ * (D_KISSFFT::inverseCepstral) and :2606-2610 (forward).  Dead code upstream (every call site is commented out,
+ * :826,832,838,1017,1021); restated because it is what "formant-envelope scaling" in the north star describes
+ *  and pinned on the real function through oracle/ref_formant.cc.
+ *   cep = irfft(log(mag + 1e-6)), lifter to the first 60 quefrencies (ends halved), envelope = exp(Re rfft(cep/N)),
+ *   mag = mag / envelope * envelope[lrint(k * env_comp)] */
+static void formant_shift(rfft *p, float *mag, float env_comp, float *cep, float *envelope) {
+    const int N = p->n, hs = N / 2;
+    const float factor = 1.0 / N;
+    for (int i = 0; i <= hs; ++i) {
+        p->packed[i].r = logf(mag[i] + 0.000001f);
+        p->packed[i].i = 0.0f;
+    }
+    rfft_inverse(p, p->packed, cep);
+    const int cutoff = 60;
+    cep[0] /= 2;
+    cep[cutoff - 1] /= 2;
+    for (int i = cutoff; i < N; ++i) cep[i] = 0.0;
+    for (int i = 0; i < cutoff; ++i) cep[i] *= factor;
+    rfft_forward(p, cep, p->packed);
+    for (int i = 0; i <= hs; ++i) envelope[i] = p->packed[i].r;
+    for (int i = 0; i <= hs; ++i) envelope[i] = expf(envelope[i]);
+    for (int i = 0; i <= hs; ++i) mag[i] /= envelope[i];
+    if (env_comp > 1.0) {
+        for (int target = 0; target <= hs; ++target) {
+            int source = lrint(target * env_comp);
+            if (source > hs) envelope[target] = 0.0;
+            else envelope[target] = envelope[source];
+        }
+    } else {
+        for (int target = hs; target > 0;) {
+            --target;
+            int source = lrint(target * env_comp);
+            envelope[target] = envelope[source];
+        }
+    }
+    for (int i = 0; i <= hs; ++i) mag[i] *= envelope[i];
+}
+
+void pvo_formant_shift(int n, float *mag, float env_comp) {
+    rfft *p = rfft_new(n);
+    float *cep = (float *)xcalloc(n, sizeof(float)), *env = (float *)xcalloc(n / 2 + 1, sizeof(float));
+    formant_shift(p, mag, env_comp, cep, env);
+    free(cep);
+    free(env);
+    rfft_free(p);
+}
+
 /* phasevocoderprocess.cc:1001-1075 */
 static void synthesise(pvo *h, chan *a) {
     const int N = (int)h->N, hs = N / 2;
     if (h->opt_formant && (h->pitch_scale != 1.0)) freq_comp(h, a, h->pitch_scale);
+    if (h->opt_cepstral && (h->pitch_scale != 1.0)) { /* formantPreserveSlice's commented-out alternative (:838) */
+        if (!h->cep) {
+            h->cep = (float *)xcalloc(N, sizeof(float));
+            h->cenv = (float *)xcalloc(hs + 1, sizeof(float));
+        }
+        formant_shift(a->fft, a->mag, h->pitch_scale, h->cep, h->cenv);
+    }
     if (h->opt_gender && (h->pitch_scale != 1.0)) {
         if (h->pitch_scale > 1) freq_comp(h, a, 0.85 * h->pitch_scale);
         else freq_comp(h, a, 1.17 * h->pitch_scale);

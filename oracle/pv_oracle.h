@@ -19,7 +19,10 @@ extern "C" {
 
 /* modes / coremodes: /root/reference/include/dafx/phasevocoder.h:22-36 */
 enum { PVO_CONSTANT = -1, PVO_NORMAL_SHIFT = 0, PVO_GENDER_CHANGE = 1, PVO_FORMANT_PRESERVE = 2,
-       PVO_VOCODER_ROSENBERG = 3, PVO_VOCODER_CHORD = 4, PVO_NORMAL_STRETCH = 5, PVO_ROBOTIC = 6, PVO_WHISPER = 7 };
+       PVO_VOCODER_ROSENBERG = 3, PVO_VOCODER_CHORD = 4, PVO_NORMAL_STRETCH = 5, PVO_ROBOTIC = 6, PVO_WHISPER = 7,
+       /* extension (not a reference mode): pitch shift with the reference's unreachable cepstral formant shift
+        * (formantShiftSlice, env_comp = pitch scale) in the place formantPreserveSlice's comment marks for it */
+       PVO_FORMANT_CEPSTRAL = 8 };
 enum { PVO_NORMAL_PV = 0, PVO_PHASE_LOCKED = 1, PVO_INT_RATIO = 2 };
 
 typedef struct pvo_config {
@@ -60,6 +63,9 @@ long pvo_get_increments(const pvo *h, int *shift, int *phase, long max);
 void pvo_hann(int n, float *w, float *area);
 void pvo_forward_polar(int n, const float *in, float *mag, float *phase);
 void pvo_inverse_polar(int n, const float *mag, const float *phase, float *out);
+/* the reference's (unreachable) cepstral formant shift of one slice's magnitudes, in place:
+ * phasevocoderprocess.cc:925-999 */
+void pvo_formant_shift(int n, float *mag, float env_comp);
 double pvo_princarg(double a);
 
 typedef struct pvo_resampler pvo_resampler;

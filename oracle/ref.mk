@@ -27,7 +27,7 @@ CSRC   := $(wildcard $(REF)/src/common/kissfft/*.c) $(REF)/src/common/speex/resa
 CXXOBJ := $(patsubst $(REF)/%.cc,$(OUT)/obj/%.o,$(CXXSRC))
 COBJ   := $(patsubst $(REF)/%.c,$(OUT)/obj/%.o,$(CSRC))
 
-all: $(OUT)/ref_driver $(OUT)/ref_kat $(OUT)/audiomod-exe
+all: $(OUT)/ref_driver $(OUT)/ref_kat $(OUT)/ref_formant $(OUT)/audiomod-exe
 
 $(OUT)/obj/%.o: $(REF)/%.cc
 	@mkdir -p $(dir $@)
@@ -45,6 +45,10 @@ $(OUT)/ref_driver: oracle/ref_driver.cc $(OUT)/libaudiomod_ref.a
 	$(CXX) $(CXXFLAGS) $(INC) $< $(OUT)/libaudiomod_ref.a -o $@ -static-libstdc++ -static-libgcc -lpthread -ldl
 
 $(OUT)/ref_kat: oracle/ref_kat.cc $(OUT)/libaudiomod_ref.a
+	$(CXX) $(CXXFLAGS) $(INC) $< $(OUT)/libaudiomod_ref.a -o $@ -static-libstdc++ -static-libgcc -lpthread -ldl
+
+# the reference's (dead-code) cepstral formant shift, called directly
+$(OUT)/ref_formant: oracle/ref_formant.cc $(OUT)/libaudiomod_ref.a
 	$(CXX) $(CXXFLAGS) $(INC) $< $(OUT)/libaudiomod_ref.a -o $@ -static-libstdc++ -static-libgcc -lpthread -ldl
 
 # The reference's own CLI (used only to capture golden WAV files for the CLI/WAV counterpart).

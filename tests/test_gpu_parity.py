@@ -318,7 +318,34 @@ def test_full_size_other_baseline_configs(name, kw):
     assert bits_equal(y[0], y[1])
 
 
+@pytest.mark.parametrize("kw", [dict(semitones=4.0), dict(semitones=-7.0), dict(semitones=7.0, fftsize=4096),
+                                dict(semitones=4.0, coremode=0), dict(semitones=0.0)])
+def test_formant_cepstral_mode(kw):
+    """extension mode: the reference's (unreachable) cepstral formant shift, oracle pinned on the real function"""
+    x = signals.voice(30000, 2, seed=91)
+    want, wc, _ = O.run_offline(x, mode="formant_cepstral", **kw)
+    got, gc = E.run_offline(x, mode="formant_cepstral", **kw)
+    assert gc == wc
+    assert rms(got, want) <= RMS_TOL
+    if kw.get("semitones"):
+        plain, _, _ = O.run_offline(x, mode="normal_pitchshift", **kw)
+        assert rms(want, plain) > 50 * RMS_TOL  # the mode really does something
+    # and through the batch API
+    import torch
+    b = E.Batch(2, x.shape[1], channels=2, mode="formant_cepstral", **kw)
+    out = b.run(torch.from_numpy(np.stack([x, x])).cuda())
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    assert rms(out[0], want) <= RMS_TOL and bits_equal(out[0], out[1])
+    b.close()
+
+
+def test_formant_cepstral_needs_a_wave_fft_size():
+    with pytest.raises(E.PvError):
+        E.PhaseVocoder(48000, 2, 1.0, 4.0, E.FORMANT_CEPSTRAL, 1, 1024)
+
+
 def test_invalid_modes_fail_loudly():
-    for mode in (8, 42, -2):
+    for mode in (9, 42, -2):
         with pytest.raises(E.PvError):
             E.PhaseVocoder(48000, 2, 1.0, 0.0, mode)

@@ -75,6 +75,18 @@ def test_resampler(kat, tag):
     assert bits_equal(np.concatenate(outs), kat[f"res{tag}_out"])
 
 
+@pytest.mark.parametrize("N", [2048, 4096])
+@pytest.mark.parametrize("tag", ["+4", "-7", "1"])
+def test_cepstral_formant_shift(kat, N, tag):
+    """formantShiftSlice (dead code upstream, called directly by oracle/_ref/ref_formant): bit-exact"""
+    L = O.lib()
+    mags = kat[f"formant{N}_in"].copy()
+    env = float(kat[f"formant{N}_{tag}_env"][0])
+    for r in range(mags.shape[0]):
+        L.pvo_formant_shift(N, mags[r].ctypes.data, env)
+    assert bits_equal(mags, kat[f"formant{N}_{tag}_out"])
+
+
 def test_princarg_range():
     L = O.lib()
     for a in np.linspace(-50, 50, 1001):

@@ -149,6 +149,24 @@ def main():
             kat[f"res{tag}_ratio"] = np.array([ratio], np.float32)
             kat[f"res{tag}_chunks"] = np.loadtxt(p("rc.txt"), dtype=np.int32).reshape(-1, 2)
             kat[f"res{tag}_out"] = np.fromfile(p("ro.f32"), np.float32)
+        # cepstral formant shift (formantShiftSlice, dead code upstream: called directly by oracle/_ref/ref_formant)
+        for N in (2048, 4096):
+            H = N // 2 + 1
+            k = np.arange(H)
+            env = np.exp(-((k - 0.06 * N) / (0.04 * N)) ** 2) + 0.6 * np.exp(-((k - 0.2 * N) / (0.06 * N)) ** 2) + 0.05
+            voiced = (env * (1 + 0.8 * np.cos(2 * np.pi * k / 9.3)) * 50 + rng.random(H)).astype(np.float32)
+            _, mp = None, kat[f"fwd{N}_magphase"]
+            mags = np.stack([voiced, voiced[::-1].copy(), (rng.random(H) * 100).astype(np.float32),
+                             np.zeros(H, np.float32), mp[0, 0], mp[1, 0]]).astype(np.float32)
+            mags.tofile(p("fm.f32"))
+            kat[f"formant{N}_in"] = mags
+            for tag, e in (("+4", 2.0 ** (np.float32(4.0) / np.float32(12.0))),
+                           ("-7", 2.0 ** (np.float32(-7.0) / np.float32(12.0))), ("1", 1.0)):
+                e = float(np.float32(e))
+                subprocess.run([os.path.join(os.path.dirname(O.REF_DRIVER), "ref_formant"), str(N), repr(e), p("fm.f32"),
+                                p("fo.f32")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                kat[f"formant{N}_{tag}_env"] = np.array([e], np.float32)
+                kat[f"formant{N}_{tag}_out"] = np.fromfile(p("fo.f32"), np.float32).reshape(-1, H)
     np.savez_compressed(os.path.join(GOLD, "kat_units.npz"), **kat)
     print("kat_units:", {k: v.shape for k, v in kat.items()})
 
