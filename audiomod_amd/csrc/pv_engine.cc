@@ -123,6 +123,11 @@ struct Core {
     int init(const pv_config &cfg, int dev, int nstreams, int chunk_slices);
     int reset_state(hipStream_t st);
     // tile geometry for outputs [ka, kb) given the slice table (P of slice t = slices[t - t_base].P)
+    // The streaming path's single-launch kernel (every mode but the vocoders, wave-FFT sizes).  Measured SLOWER
+    // than one launch per stage -- 93 vs 70 us per 480-frame stereo call: the five launches are asynchronous and
+    // overlap the kernels, whereas one workgroup runs the stages' latencies back to back on one CU -- so it is
+    // opt-in: AUDIOMOD_PV_STREAM_LAUNCHES=single.
+    bool can_single_launch() const;
     int build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64_t t_end, int64_t ka, int64_t kb,
                     int32_t p_index_base, std::vector<OlaTile> &tiles, std::vector<float> &wacc) const;
     void launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
@@ -132,7 +137,8 @@ struct Core {
                       const OlaArgs *prev_ola = nullptr /* previous chunk's OLA, launched beside this chunk's chain */,
                       OlaArgs *defer = nullptr /* receives this chunk's OLA instead of launching it */,
                       hipStream_t st_chain = nullptr /* the chain's own stream (with ev_match / ev_chain) */,
-                      hipEvent_t ev_match = nullptr, hipEvent_t ev_chain = nullptr) const;
+                      hipEvent_t ev_match = nullptr, hipEvent_t ev_chain = nullptr,
+                      bool single_launch = false) const; // single_launch: the streaming path's one-workgroup kernel
     // Phase-locked batch path: the rotation chain of chunk i (a few waves per row, pure latency) runs on a second
     // HIP stream while the main stream runs the overlap-add tiles of chunk i-1.
     bool can_overlap_chain() const {
@@ -300,6 +306,26 @@ int Core::reset_state(hipStream_t st) {
     return PV_OK;
 }
 
+bool Core::can_single_launch() const {
+    static const bool on = [] {
+        const char *e = getenv("AUDIOMOD_PV_STREAM_LAUNCHES");
+        return e && strcmp(e, "single") == 0;
+    }();
+    if (!on || d.vocoder) return false;
+    StreamArgs probe{};
+    probe.aa.tb = tb;
+    probe.ma.hs = d.hs;
+    probe.ma.PKP = PKP;
+    probe.qa.hs = d.hs;
+    probe.qa.PKP = PKP;
+    probe.coremode = 1;
+    probe.oa.tab_bytes = !d.resample ? 0
+                         : d.interp  ? d.oversample * (d.filt_len + 1) * 16
+                                     : (int)((d.sinc.size() * sizeof(float) + 15) & ~(size_t)15);
+    probe.oa.lds_floats = ola_lds_floats;
+    return stream_kernel_supported(probe);
+}
+
 int Core::build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64_t t_end, int64_t ka, int64_t kb,
                       int32_t p_index_base, std::vector<OlaTile> &tiles, std::vector<float> &wacc) const {
     // slices[t - t_base] must exist for every t in [max(t_base, t_end - FR), t_end); a tile that needed an
@@ -391,7 +417,8 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
                         int ntiles, const int64_t *d_P, const float *d_wacc, const float *d_whisper,
                         const InAddr *carrier, float *out, int64_t out_stride_row, int64_t k_base,
                         hipStream_t st, hipEvent_t *ev, const OlaArgs *prev_ola, OlaArgs *defer,
-                        hipStream_t st_chain, hipEvent_t ev_match, hipEvent_t ev_chain) const {
+                        hipStream_t st_chain, hipEvent_t ev_match, hipEvent_t ev_chain, bool single_launch) const {
+    StreamArgs fused{};
     const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder;
     const int cm = bypass ? -1 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
     auto rec = [&](int i) {
@@ -414,7 +441,8 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     aa.peaks = peaks.p;
     aa.npk = npk.p;
     rec(2 * PV_K_ANALYZE);
-    launch_analyze(aa, st);
+    if (single_launch) fused.aa = aa;
+    else launch_analyze(aa, st);
     if (d.vocoder && carrier) {
         // the carrier is one more (data-independent) row: same analysis, its own planes
         AnalyzeArgs ca = aa;
@@ -448,7 +476,8 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ma.recs = recs.p;
         ma.modes = modes.p;
         rec(2 * PV_K_MATCH);
-        launch_match(ma, st);
+        if (single_launch) fused.ma = ma;
+        else launch_match(ma, st);
         rec(2 * PV_K_MATCH + 1);
         SeqArgs qa{};
         qa.N = d.N;
@@ -474,7 +503,9 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         qa.st_kind = st_kind.p;
         qa.st_rot = st_rot.p;
         qa.st_po = st_po.p;
-        if (st_chain && st_chain != st) {
+        if (single_launch) {
+            fused.qa = qa;
+        } else if (st_chain && st_chain != st) {
             // chain on its own stream: after this chunk's match, beside the previous chunk's overlap-add
             (void)hipEventRecord(ev_match, st);
             (void)hipStreamWaitEvent(st_chain, ev_match, 0);
@@ -513,7 +544,8 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         pa.st_pp = st_pp.p;
         pa.st_po = st_po.p;
         rec(2 * PV_K_PROP);
-        launch_prop(pa, st);
+        if (single_launch) fused.pa = pa;
+        else launch_prop(pa, st);
         rec(2 * PV_K_PROP + 1);
     }
 
@@ -560,11 +592,13 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ca.inv_n = d.inv_n;
         ca.mag = mag.p;
         rec(2 * PV_K_CEPSTRAL);
-        launch_cepstral(ca, st);
+        if (single_launch) fused.ca = ca;
+        else launch_cepstral(ca, st);
         rec(2 * PV_K_CEPSTRAL + 1);
     }
     rec(2 * PV_K_SYNTH);
-    launch_synth(sa, st);
+    if (single_launch) fused.sa = sa;
+    else launch_synth(sa, st);
     rec(2 * PV_K_SYNTH + 1);
 
     OlaArgs oa{};
@@ -594,7 +628,12 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     oa.out = out;
     oa.out_stride_row = out_stride_row;
     oa.k_base = k_base;
-    if (defer) {
+    if (single_launch) {
+        fused.oa = oa;
+        fused.coremode = cm;
+        fused.cepstral = d.cepstral ? 1 : 0;
+        launch_stream(fused, st);
+    } else if (defer) {
         *defer = oa; // launched later, beside the next chunk's chain
     } else if (ntiles > 0) {
         rec(2 * PV_K_OLA_RESAMPLE);
@@ -1095,7 +1134,8 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
                        reinterpret_cast<const OlaTile *>(e->d_desc.p + t_off_bytes), (int)tiles.size(),
                        reinterpret_cast<const int64_t *>(e->d_desc.p + p_off_bytes),
                        reinterpret_cast<const float *>(e->d_desc.p + w_off_bytes), e->d_whisper.p,
-                       c.d.vocoder ? &car : nullptr, e->d_out.p, e->out_cap, ka, e->stream, nullptr);
+                       c.d.vocoder ? &car : nullptr, e->d_out.p, e->out_cap, ka, e->stream, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, c.can_single_launch());
         (void)p_off_bytes;
         const int64_t cnt = kb - ka;
         if (cnt > 0)

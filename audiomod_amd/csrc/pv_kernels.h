@@ -180,6 +180,22 @@ struct OlaArgs {
     int64_t k_base;         // out index = k - k_base
 };
 
+// Everything one streaming call needs, for the single-launch kernel of the drop-in path (pv_stream_kernel): the
+// argument blocks of the stages it chains.  coremode: 1 = match + chain, 0 = per-bin propagation, anything else =
+// no phase stage (coremode 2 and the modes that bypass it).
+struct StreamArgs {
+    AnalyzeArgs aa;
+    MatchArgs ma;
+    SeqArgs qa;
+    PropArgs pa;
+    CepstralArgs ca;
+    SynthArgs sa;
+    OlaArgs oa;
+    int coremode, cepstral;
+};
+bool stream_kernel_supported(const StreamArgs &s);  // wave-FFT sizes only (nc 1024 / 2048)
+void launch_stream(const StreamArgs &s, hipStream_t st);
+
 void launch_analyze(const AnalyzeArgs &a, hipStream_t st);
 void launch_match(const MatchArgs &a, hipStream_t st);
 void launch_seq(const SeqArgs &a, hipStream_t st);

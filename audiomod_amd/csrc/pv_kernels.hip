@@ -260,14 +260,12 @@ template <int WPB> __device__ __forceinline__ bool block_to_row_slice_w(int Tn, 
     return row < rows && tl < Tn;
 }
 
-template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyze_wave_kernel(const AnalyzeArgs a) {
+// (the body is a device function of (row, slice) so that the single-launch streaming kernel can call it too)
+template <int NC>
+__device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const int row, const int tl, cf *lds) {
     using W = WF<NC>;
     constexpr int N = 2 * NC, hs = NC, R = W::R;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    cf *lds = reinterpret_cast<cf *>(smem_raw) + wave * W::LDS_CF;
-    int row, tl;
-    if (!block_to_row_slice_w<WPB>(a.Tn, a.rows, row, tl)) return; // wave-uniform
+    const int lane = threadIdx.x & 63;
     const DevTables &tb = a.tb;
     const int64_t t = a.t0 + tl;
     const int slot = ring_slot(a.s0, tl, a.TR);
@@ -461,6 +459,14 @@ template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyz
     for (int i = lane; 2 * i < running; i += 64) pk32[i] = slist32[i];
 }
 
+template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyze_wave_kernel(const AnalyzeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cf *lds = reinterpret_cast<cf *>(smem_raw) + (threadIdx.x >> 6) * WF<NC>::LDS_CF;
+    int row, tl;
+    if (!block_to_row_slice_w<WPB>(a.Tn, a.rows, row, tl)) return; // wave-uniform
+    analyze_wave_role<NC>(a, row, tl, lds);
+}
+
 // kernels may need more than the default 64 KiB of dynamic LDS at the largest FFT sizes
 template <typename K> static void allow_big_lds(K kernel, bool &done) {
     if (done) return;
@@ -533,8 +539,7 @@ __host__ __device__ inline size_t match_wave_lds(int hs, int PKP) {
     return bm + 3 * (((size_t)PKP * sizeof(uint16_t) + 15) & ~(size_t)15);
 }
 
-__global__ __launch_bounds__(kMatchThreads) void pv_match_kernel(const MatchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+__device__ __forceinline__ void match_wave_role(const MatchArgs &a, const int row, const int tl, char *wbase) {
     // bitmaps instead of sorted-list searches: "nearest previous peak" is a find-first-set around p2 in the
     // previous step's peak bitmap; "region of p1" is a prefix popcount over the boundary bitmap of the previous
     // same-channel step (2-4 independent LDS reads instead of two 9-step dependent binary searches).
@@ -542,8 +547,6 @@ __global__ __launch_bounds__(kMatchThreads) void pv_match_kernel(const MatchArgs
     // peak counts and, speculatively and 16 bytes per lane, the three peak lists it may need; (2) the phases at
     // the matched bins of up to six peaks per lane at once; (3) the records out.
     const int nw = (a.hs + 63) >> 6;
-    const int wave = threadIdx.x >> 6;
-    char *wbase = smem_raw + (size_t)wave * match_wave_lds(a.hs, a.PKP);
     unsigned long long *bprev = reinterpret_cast<unsigned long long *>(wbase);    // [nw] peaks of the previous step
     unsigned long long *bbnd = bprev + nw;                                        // [nw] region boundaries, same channel
     int *pre = reinterpret_cast<int *>(bbnd + nw);                                // [nw] boundaries before each word
@@ -552,9 +555,7 @@ __global__ __launch_bounds__(kMatchThreads) void pv_match_kernel(const MatchArgs
     uint16_t *lcur = reinterpret_cast<uint16_t *>(lbase);                         // [PKP] this step's peaks
     uint16_t *lprev = reinterpret_cast<uint16_t *>(lbase + lpitch);               // [PKP] previous step's peaks
     uint16_t *lsame = reinterpret_cast<uint16_t *>(lbase + 2 * lpitch);           // [PKP] previous same-channel step's
-    const int tl = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave), row = blockIdx.y, nt = 64;
-    const int tid = threadIdx.x & 63;
-    if (tl >= a.Tn) return; // wave-uniform
+    const int nt = 64, tid = threadIdx.x & 63;
     const int s = row / a.C, c = row - s * a.C;
     const int64_t t = a.t0 + tl;
     const int slot = ring_slot(a.s0, tl, a.TR), pslot = ring_prev(slot, a.TR);
@@ -649,6 +650,14 @@ __global__ __launch_bounds__(kMatchThreads) void pv_match_kernel(const MatchArgs
             a.recs[plane * a.PKP + p] = r; // round trip 3
         }
     }
+}
+
+__global__ __launch_bounds__(kMatchThreads) void pv_match_kernel(const MatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6;
+    const int tl = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (tl >= a.Tn) return; // wave-uniform
+    match_wave_role(a, blockIdx.y, tl, smem_raw + (size_t)wave * match_wave_lds(a.hs, a.PKP));
 }
 
 void launch_match(const MatchArgs &a, hipStream_t st) {
@@ -849,9 +858,7 @@ void launch_seq(const SeqArgs &a, hipStream_t st) {
 // --------------------------------------------------------------------------------------------
 constexpr int kPropThreads = 256;
 
-__global__ __launch_bounds__(kPropThreads) void pv_prop_kernel(const PropArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
-    if (i >= a.hs) return;
+__device__ __forceinline__ void prop_role(const PropArgs &a, const int row, const int i) {
     const int c = row % a.C;
     float pp = a.st_pp[(int64_t)row * a.hs + i], po = a.st_po[(int64_t)row * a.hs + i];
     const float omega = (float)((a.two_pi_hop * (double)i) / (double)a.N);
@@ -875,6 +882,11 @@ __global__ __launch_bounds__(kPropThreads) void pv_prop_kernel(const PropArgs a)
     }
     a.st_pp[(int64_t)row * a.hs + i] = pp;
     a.st_po[(int64_t)row * a.hs + i] = po;
+}
+
+__global__ __launch_bounds__(kPropThreads) void pv_prop_kernel(const PropArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.hs) prop_role(a, blockIdx.y, i);
 }
 
 void launch_prop(const PropArgs &a, hipStream_t st) {
@@ -1021,17 +1033,11 @@ __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a
 // synthesis, wave-per-frame variant.  The wave-private LDS region is reused four times:
 // [output phases + rot/peak lists] -> [spectrum X] -> [butterfly-ordered input] -> [time-domain frame].
 // --------------------------------------------------------------------------------------------
-// (N = 2048 is asked to fit four waves per SIMD, 128 VGPRs; the compiler gets there without spilling)
-template <int NC, int WPB>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(NC == 1024 ? 4 : 1))) void
-pv_synth_wave_kernel(const SynthArgs a) {
+template <int NC>
+__device__ __forceinline__ void synth_wave_role(const SynthArgs &a, const int row, const int tl, cf *lds) {
     using W = WF<NC>;
     constexpr int N = 2 * NC, hs = NC, R = W::R;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    cf *lds = reinterpret_cast<cf *>(smem_raw) + wave * W::LDS_CF;
-    int row, tl;
-    if (!block_to_row_slice_w<WPB>(a.Tn, a.rows, row, tl)) return; // wave-uniform
+    const int lane = threadIdx.x & 63;
     const DevTables &tb = a.tb;
     const int64_t t = a.t0 + tl;
     const int64_t plane = (int64_t)row * a.TR + ring_slot(a.s0, tl, a.TR);
@@ -1342,6 +1348,17 @@ pv_synth_wave_kernel(const SynthArgs a) {
     }
 }
 
+// (N = 2048 is asked to fit four waves per SIMD, 128 VGPRs; the compiler gets there without spilling)
+template <int NC, int WPB>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(NC == 1024 ? 4 : 1))) void
+pv_synth_wave_kernel(const SynthArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cf *lds = reinterpret_cast<cf *>(smem_raw) + (threadIdx.x >> 6) * WF<NC>::LDS_CF;
+    int row, tl;
+    if (!block_to_row_slice_w<WPB>(a.Tn, a.rows, row, tl)) return; // wave-uniform
+    synth_wave_role<NC>(a, row, tl, lds);
+}
+
 void launch_synth(const SynthArgs &a, hipStream_t st) {
     if (a.tb.nc == 1024 || a.tb.nc == 2048) {
         if (a.tb.nc == 1024) {
@@ -1377,14 +1394,11 @@ void launch_synth(const SynthArgs &a, hipStream_t st) {
 //   envelope = exp(Re kiss_fftr(cep));  mag = mag / envelope * envelope[lrint(k * env_comp)]
 // One wave per (row, slice), both transforms through the wave-FFT core in the wave's LDS region.
 // --------------------------------------------------------------------------------------------
-template <int NC> __global__ __launch_bounds__(64) void pv_cepstral_wave_kernel(const CepstralArgs a) {
+template <int NC>
+__device__ __forceinline__ void cepstral_wave_role(const CepstralArgs &a, const int row, const int tl, cf *lds) {
     using W = WF<NC>;
     constexpr int hs = NC, R = W::R, J = NC / 128, QB = NC / 256, kCut = 60;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int lane = threadIdx.x & 63;
-    cf *lds = reinterpret_cast<cf *>(smem_raw);
-    int row, tl;
-    if (!block_to_row_slice_w<1>(a.Tn, a.rows, row, tl)) return; // wave-uniform
     const DevTables &tb = a.tb;
     const int64_t plane = (int64_t)row * a.TR + ring_slot(a.s0, tl, a.TR);
     float *__restrict__ mag = a.mag + plane * tb.HP;
@@ -1564,6 +1578,13 @@ template <int NC> __global__ __launch_bounds__(64) void pv_cepstral_wave_kernel(
         *reinterpret_cast<float4 *>(mag + k0) = o;
     }
     if (lane == 0) mag[hs] = (mny / senv[hs]) * shifted(hs);
+}
+
+template <int NC> __global__ __launch_bounds__(64) void pv_cepstral_wave_kernel(const CepstralArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    int row, tl;
+    if (!block_to_row_slice_w<1>(a.Tn, a.rows, row, tl)) return; // wave-uniform
+    cepstral_wave_role<NC>(a, row, tl, reinterpret_cast<cf *>(smem_raw));
 }
 
 void launch_cepstral(const CepstralArgs &a, hipStream_t st) {
@@ -1751,6 +1772,85 @@ void launch_ola(const OlaArgs &a, hipStream_t st) {
     static bool big = false;
     allow_big_lds(pv_ola_kernel, big);
     hipLaunchKernelGGL(pv_ola_kernel, dim3(a.ntiles, a.rows), dim3(kTileOut), lds, st, a);
+}
+
+// --------------------------------------------------------------------------------------------
+// The drop-in streaming path in ONE launch (opt-in, AUDIOMOD_PV_STREAM_LAUNCHES=single).  A 480-frame call of a
+// stereo stream triggers two or three slices per channel: far too little work to fill the chip, and with one
+// launch per stage the host spends ~7 us on each of five launches.  One workgroup of eight waves runs the stages
+// back to back instead -- the same device functions as the batch kernels, frames / steps spread over the waves,
+// rows and tiles looped -- with a workgroup barrier (and a fence: the stages hand data over through global
+// memory) between stages.  Measured on MI355X it LOSES (93 vs 70 us per call, 513 vs 242 us at 4800-frame
+// calls): the separate launches are asynchronous and already overlap the kernels, while a single workgroup pays
+// every stage's latency in sequence on one CU.  Kept as a tested alternative, off by default.
+// --------------------------------------------------------------------------------------------
+constexpr int kStreamThreads = 512;
+
+__device__ __forceinline__ void stage_handoff() {
+    __threadfence();                  // later stages read what other waves of this workgroup wrote to global memory
+    __builtin_amdgcn_s_dcache_inv();  // ... some of it through the scalar cache (wave-uniform counts and modes)
+    __syncthreads();
+}
+
+template <int NC> __global__ __launch_bounds__(kStreamThreads) void pv_stream_kernel(const StreamArgs s) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = kStreamThreads / 64;
+    const int Tn = s.aa.Tn, rows = s.aa.rows, work = rows * Tn;
+    cf *wlds = reinterpret_cast<cf *>(smem_raw) + wave * WF<NC>::LDS_CF;
+    for (int i = wave; i < work; i += nw) analyze_wave_role<NC>(s.aa, i / Tn, i % Tn, wlds);
+    stage_handoff();
+    if (s.coremode == 1) {
+        // (slice-major order is not needed: a step only reads peak lists, all written by now)
+        for (int i = wave; i < work; i += nw)
+            match_wave_role(s.ma, i / Tn, i % Tn, smem_raw + (size_t)wave * match_wave_lds(s.ma.hs, s.ma.PKP));
+        stage_handoff();
+        for (int row = 0; row < rows; ++row) {
+            seq_role(s.qa, row, smem_raw);
+            stage_handoff();
+        }
+    } else if (s.coremode == 0) {
+        for (int row = 0; row < rows; ++row)
+            for (int i = threadIdx.x; i < s.pa.hs; i += kStreamThreads) prop_role(s.pa, row, i);
+        stage_handoff();
+    }
+    if (s.cepstral) {
+        for (int i = wave; i < work; i += nw) cepstral_wave_role<NC>(s.ca, i / Tn, i % Tn, wlds);
+        stage_handoff();
+    }
+    for (int i = wave; i < work; i += nw) synth_wave_role<NC>(s.sa, i / Tn, i % Tn, wlds);
+    stage_handoff();
+    for (int tile = 0; tile < s.oa.ntiles; ++tile)
+        for (int row = 0; row < rows; ++row) {
+            ola_role(s.oa, tile, row, smem_raw);
+            __syncthreads();
+        }
+}
+
+static size_t stream_lds_bytes(const StreamArgs &s) {
+    const size_t per_wave = (s.aa.tb.nc == 1024 ? WF<1024>::LDS_CF : WF<2048>::LDS_CF) * sizeof(cf);
+    size_t lds = (kStreamThreads / 64) * per_wave;
+    const size_t m = (kStreamThreads / 64) * match_wave_lds(s.ma.hs, s.ma.PKP);
+    if (s.coremode == 1 && m > lds) lds = m;
+    if (s.coremode == 1 && seq_lds_bytes(s.qa) > lds) lds = seq_lds_bytes(s.qa);
+    if (ola_lds_bytes(s.oa) > lds) lds = ola_lds_bytes(s.oa);
+    return lds;
+}
+
+bool stream_kernel_supported(const StreamArgs &s) {
+    return (s.aa.tb.nc == 1024 || s.aa.tb.nc == 2048) && stream_lds_bytes(s) <= 160 * 1024 - 512;
+}
+
+void launch_stream(const StreamArgs &s, hipStream_t st) {
+    const size_t lds = stream_lds_bytes(s);
+    if (s.aa.tb.nc == 1024) {
+        static bool big1 = false;
+        allow_big_lds(pv_stream_kernel<1024>, big1);
+        hipLaunchKernelGGL((pv_stream_kernel<1024>), dim3(1), dim3(kStreamThreads), lds, st, s);
+    } else {
+        static bool big2 = false;
+        allow_big_lds(pv_stream_kernel<2048>, big2);
+        hipLaunchKernelGGL((pv_stream_kernel<2048>), dim3(1), dim3(kStreamThreads), lds, st, s);
+    }
 }
 
 } // namespace pv

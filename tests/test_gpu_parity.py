@@ -4,6 +4,8 @@
 Tolerance (BASELINE.json north_star): output within 1e-4 RMS of the reference on identical input.
 Everything that involves no device transcendental on a non-trivial argument must be BIT-exact
 (integer scheduling, FFT, magnitudes, OLA, resampler)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -15,6 +17,7 @@ from tests.helpers import bits_equal, e2e_cases, load_e2e
 pytestmark = pytest.mark.gpu
 
 RMS_TOL = 1e-4
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def rms(a, b):
@@ -239,6 +242,32 @@ def test_streaming_long_run_state_carry():
     got, gc = E.run_offline(x, semitones=7.0, mode="gender_change", block=256)
     assert gc == wc
     assert rms(got, want) <= RMS_TOL
+
+
+def test_single_launch_streaming_kernel():
+    """The opt-in one-launch-per-call kernel of the streaming path (AUDIOMOD_PV_STREAM_LAUNCHES=single; read once
+    per process, hence the child process) must give the same results as one launch per stage."""
+    import subprocess
+    import sys
+    code = """
+import numpy as np, sys
+sys.path.insert(0, %r)
+from audiomod_amd import engine as E, signals
+from oracle import oracle_py as O
+x = signals.voice(40000, 2, seed=5)
+for kw in (dict(semitones=4.0), dict(semitones=-7.0, mode="formant_pitchshift"), dict(semitones=3.0, coremode=0),
+           dict(mode="time_stretch", time_ratio=1.5, fftsize=4096, flush=False), dict(mode="robotic"),
+           dict(mode="formant_cepstral", semitones=5.0)):
+    want, wc, _ = O.run_offline(x, **kw)
+    got, gc = E.run_offline(x, **kw)
+    assert gc == wc, kw
+    e = float(np.sqrt(np.mean((got.astype(np.float64) - want) ** 2)))
+    assert e <= 1e-4, (kw, e)
+print("single-launch ok")
+""" % (ROOT,)
+    env = dict(os.environ, AUDIOMOD_PV_STREAM_LAUNCHES="single")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "single-launch ok" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("kw", [dict(mode="constant"), dict(mode="constant", fftsize=4096), dict(mode="whisper"),
