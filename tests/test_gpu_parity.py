@@ -244,6 +244,24 @@ def test_streaming_long_run_state_carry():
     assert rms(got, want) <= RMS_TOL
 
 
+@pytest.mark.parametrize("frames", [30001, 30002, 30003])
+def test_batch_rows_at_unaligned_offsets(frames):
+    """Batch rows start (stream * channels + channel) * frames floats into the buffer: with frames not a multiple
+    of four the analysis kernel's aligned 16-byte frame loads begin in the previous row's tail and every
+    sub-alignment of the pre-delayed window copies is exercised."""
+    import torch
+    x = np.stack([signals.voice(frames, 2, seed=40 + s) for s in range(3)])
+    b = E.Batch(3, frames, channels=2, semitones=4.0)
+    out = b.run(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    b.close()
+    for s in range(3):
+        want, _, _ = O.run_offline(x[s], semitones=4.0)
+        assert out[s].shape == want.shape
+        assert rms(out[s], want) <= RMS_TOL
+
+
 def test_single_launch_streaming_kernel():
     """The opt-in one-launch-per-call kernel of the streaming path (AUDIOMOD_PV_STREAM_LAUNCHES=single; read once
     per process, hence the child process) must give the same results as one launch per stage."""
