@@ -483,7 +483,7 @@ void launch_analyze(const AnalyzeArgs &a, hipStream_t st) {
             hipLaunchKernelGGL((pv_analyze_wave_kernel<1024, WPB>), dim3(grid), dim3(64 * WPB),
                                WPB * WF<1024>::LDS_CF * sizeof(cf), st, a);
         } else {
-            constexpr int WPB = 4;
+            constexpr int WPB = 1;
             const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
             static bool big = false;
             allow_big_lds(pv_analyze_wave_kernel<2048, WPB>, big);
@@ -1330,20 +1330,37 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a, const int ro
                 make_float4(z0.x * ww[j].x, z0.y * ww[j].y, z1.x * ww[j].z, z1.y * ww[j].w);
         }
     } else {
+        // no room to fetch a pass ahead, but the lane-major tables still turn each pass's twiddle gathers into a
+        // few contiguous 16-byte loads
         wave_sync();
         wf_fft_pass<W, 0, true>(v, lane, lds, tw);
         wave_sync();
-        wf_fft_pass<W, 1, true>(v, lane, lds, tw);
+        {
+            WfTwRaw<W, 1> r1;
+            wf_fetch_pass_tw<W, 1>(r1, lane, twl);
+            wf_unpack_pass_tw<W, 1>(T1, r1);
+            wf_fft_pass_tw<W, 1, true>(v, lane, lds, T1);
+        }
         wave_sync();
-        wf_fft_pass<W, 2, true>(v, lane, lds, tw);
+        {
+            WfTwRaw<W, 2> r2;
+            wf_fetch_pass_tw<W, 2>(r2, lane, twl);
+            wf_unpack_pass_tw<W, 2>(T2, r2);
+            wf_fft_pass_tw<W, 2, true>(v, lane, lds, T2);
+        }
+        // (v is dead now: the whole window fits in its registers, fetched before the frame's first store, and the
+        // frame leaves 16 bytes per lane like the other variant's)
+        float4 ww[NC / 128];
+#pragma unroll
+        for (int j = 0; j < NC / 128; ++j) ww[j] = *reinterpret_cast<const float4 *>(w + 4 * (lane + 64 * j));
         wave_sync();
-#pragma unroll 4
-        for (int j = 0; j < NC / 64; ++j) {
-            const int i = 2 * (lane + 64 * j);
+#pragma unroll
+        for (int j = 0; j < NC / 128; ++j) {
+            const int i = 4 * (lane + 64 * j);
             const int e = ((i + hs) & (N - 1)) >> 1;
-            const cf z = lds[W::pad(e)];
-            const float2 ww = *reinterpret_cast<const float2 *>(w + i);
-            *reinterpret_cast<float2 *>(out + i) = make_float2(z.x * ww.x, z.y * ww.y);
+            const cf z0 = lds[W::pad(e)], z1 = lds[W::pad(e) + 1];
+            *reinterpret_cast<float4 *>(out + i) =
+                make_float4(z0.x * ww[j].x, z0.y * ww[j].y, z1.x * ww[j].z, z1.y * ww[j].w);
         }
     }
 }
@@ -1369,7 +1386,7 @@ void launch_synth(const SynthArgs &a, hipStream_t st) {
             hipLaunchKernelGGL((pv_synth_wave_kernel<1024, WPB>), dim3(grid), dim3(64 * WPB),
                                WPB * WF<1024>::LDS_CF * sizeof(cf), st, a);
         } else {
-            constexpr int WPB = 4;
+            constexpr int WPB = 1;
             const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
             static bool big2 = false;
             allow_big_lds(pv_synth_wave_kernel<2048, WPB>, big2);
