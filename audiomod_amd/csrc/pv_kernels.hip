@@ -1088,6 +1088,10 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a, const int ro
 #pragma unroll
             for (int q = 0; q < QB / 2; ++q) mreg[q] = *reinterpret_cast<const float4 *>(mag + 4 * (lane + 64 * q));
             mnyq = mag[hs];
+        } else if (a.do_freq_comp) { // freqCompSlice gathers across bins: the whole row, staged in LDS below
+#pragma unroll
+            for (int q = 0; q < QB; ++q) mreg[q] = *reinterpret_cast<const float4 *>(mag + 4 * (lane + 64 * q));
+            mnyq = mag[hs];
         }
     };
     uint16_t pkr[QP];
@@ -1156,11 +1160,17 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a, const int ro
                                   rotated(base[q].w, 3));
         }
     }
+    float *smg = sph + hs + 4; // [hs + 1] magnitudes for the gather (over the rotation / peak lists, done with)
     if (!plain) {
         wave_sync();
 #pragma unroll
         for (int q = 0; q < QB; ++q) *reinterpret_cast<float4 *>(sph + 4 * (lane + 64 * q)) = base[q];
         if (lane == 0) sph[hs] = pnyq;
+        if (a.do_freq_comp) {
+#pragma unroll
+            for (int q = 0; q < QB; ++q) *reinterpret_cast<float4 *>(smg + 4 * (lane + 64 * q)) = mreg[q];
+            if (lane == 0) smg[hs] = mnyq;
+        }
         wave_sync();
     }
 
@@ -1182,15 +1192,15 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a, const int ro
                     mg = 0.f;
                     p = 0.f;
                 } else {
-                    mg = mag[src];
+                    mg = smg[src];
                     p = sph[src] + (float)((a.two_pi_hop * (double)(k - src)) / Nd);
                 }
             } else if (k < hs) {
                 const int src = __float2int_rn((float)k * a.freq_comp);
-                mg = mag[src];
+                mg = smg[src];
                 p = sph[src] + (float)((a.two_pi_hop * (double)(k - src)) / Nd);
             } else {
-                mg = mag[k];
+                mg = smg[k];
                 p = sph[k];
             }
             mg *= a.fixed_gain;
