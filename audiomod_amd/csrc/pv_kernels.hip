@@ -859,26 +859,41 @@ void launch_seq(const SeqArgs &a, hipStream_t st) {
 constexpr int kPropThreads = 256;
 
 __device__ __forceinline__ void prop_role(const PropArgs &a, const int row, const int i) {
+    // Only out = princarg(prev_out + advance) is a recurrence: the advance of a step depends on the analysis phases
+    // of that step and the one before, which are data.  So the slices are taken four at a time -- their phases
+    // loaded together, their advances computed side by side -- and only the last princarg of each forms the chain.
     const int c = row % a.C;
+    const float *__restrict__ ph = a.phase;
+    float *__restrict__ op = a.outphase;
     float pp = a.st_pp[(int64_t)row * a.hs + i], po = a.st_po[(int64_t)row * a.hs + i];
     const float omega = (float)((a.two_pi_hop * (double)i) / (double)a.N);
     const float hop_f = (float)a.hop;
-    for (int tl = 0; tl < a.Tn; ++tl) {
-        const int64_t t = a.t0 + tl;
-        const int64_t plane = (int64_t)row * a.TR + ring_slot(a.s0, tl, a.TR);
-        const float phi = a.phase[plane * a.HP + i];
-        float outv;
-        if (t == 0 && c == 0) {
-            outv = phi; // firstentry: only the very first step of the stream (function-static in the reference)
-        } else {
-            const float d1 = phi - pp - omega;
-            const float delta = (float)((double)omega + princarg((double)d1));
-            const float advance = delta * (float)a.phase_inc[tl] / hop_f;
-            outv = (float)princarg((double)(po + advance));
+    constexpr int kU = 4;
+    for (int tl0 = 0; tl0 < a.Tn; tl0 += kU) {
+        float phi[kU], adv[kU];
+        int64_t plane[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int tl = tl0 + u < a.Tn ? tl0 + u : a.Tn - 1;
+            plane[u] = (int64_t)row * a.TR + ring_slot(a.s0, tl, a.TR);
+            phi[u] = ph[plane[u] * a.HP + i];
         }
-        pp = phi;
-        po = outv;
-        a.outphase[plane * a.HP + i] = outv;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int tl = tl0 + u < a.Tn ? tl0 + u : a.Tn - 1;
+            const float d1 = phi[u] - (u ? phi[u - 1] : pp) - omega;
+            const float delta = (float)((double)omega + princarg((double)d1));
+            adv[u] = delta * (float)a.phase_inc[tl] / hop_f;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (tl0 + u >= a.Tn) break;
+            // firstentry: only the very first step of the stream (function-static in the reference)
+            const float outv = (a.t0 + tl0 + u == 0 && c == 0) ? phi[u] : (float)princarg((double)(po + adv[u]));
+            pp = phi[u];
+            po = outv;
+            op[plane[u] * a.HP + i] = outv;
+        }
     }
     a.st_pp[(int64_t)row * a.hs + i] = pp;
     a.st_po[(int64_t)row * a.hs + i] = po;
