@@ -103,6 +103,7 @@ struct Core {
     Derived d;
     int device = 0, S = 0, C = 0, rows = 0;
     int Tc = 0, TR = 0, FR = 0, HP = 0, pkmax = 0, PKP = 0, lookback = 0;
+    bool pipelined_planes = false; // set before init() by the batch engine
     int ola_lds_floats = 0;
     int otab_off = 0, wacc_pitch = 0; // layout of one tile's row of host-planned values (pv_kernels.h OlaArgs)
     DevTables tb{};
@@ -130,25 +131,31 @@ struct Core {
     bool can_single_launch() const;
     int build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64_t t_end, int64_t ka, int64_t kb,
                     int32_t p_index_base, std::vector<OlaTile> &tiles, std::vector<float> &wacc) const;
+    // part: 0 = the whole chunk on `st`; 1 = its front (analysis, match, and the rotation chain handed to
+    // st_chain); 2 = its back (synthesis, overlap-add, after waiting for the chain).  Parts 1 and 2 are the two
+    // halves of the pipelined phase-locked batch path (pv_batch_run).
     void launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
                       int ntiles, const int64_t *d_P, const float *d_wacc, const float *d_whisper,
                       const InAddr *carrier, float *out, int64_t out_stride_row, int64_t k_base,
-                      hipStream_t st, hipEvent_t *ev /* 2*PV_NUM_KERNELS events or null */,
-                      const OlaArgs *prev_ola = nullptr /* previous chunk's OLA, launched beside this chunk's chain */,
-                      OlaArgs *defer = nullptr /* receives this chunk's OLA instead of launching it */,
+                      hipStream_t st, hipEvent_t *ev /* 2*PV_NUM_KERNELS events or null */, int part = 0,
                       hipStream_t st_chain = nullptr /* the chain's own stream (with ev_match / ev_chain) */,
                       hipEvent_t ev_match = nullptr, hipEvent_t ev_chain = nullptr,
                       bool single_launch = false) const; // single_launch: the streaming path's one-workgroup kernel
-    // Phase-locked batch path: the rotation chain of chunk i (a few waves per row, pure latency) runs on a second
-    // HIP stream while the main stream runs the overlap-add tiles of chunk i-1.
-    bool can_overlap_chain() const {
-        const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder;
-        // Off by default: measured on MI355X the chain runs 2.7x slower beside the overlap-add tiles (0.152 vs
-        // 0.055 ms per launch, whatever the stream / wave priority and prefetch depth) and the reordering costs the
-        // synthesis kernel its cache-warm inputs, so the overlapped pipeline is 5 % SLOWER end to end.
-        if (!getenv("AUDIOMOD_PV_OVERLAP_CHAIN")) return false;
-        return !bypass && d.cfg.coremode == 1;
+    // Phase-locked batch path: the rotation chain of chunk i (one workgroup per row, a few waves, pure latency:
+    // it leaves 95 % of the chip idle) runs on a second HIP stream while the main stream synthesises and
+    // overlap-adds chunk i-1 and analyses and matches chunk i+1.  The slice-indexed planes then hold two chunks.
+    // AUDIOMOD_PV_PIPELINE=0 turns it off (one stream, chunk after chunk).
+    static bool pipeline_wanted(const pv_config &cfg) {
+        const char *e = getenv("AUDIOMOD_PV_PIPELINE");
+        if (e && atoi(e) == 0) return false;
+        const bool phase_stage = cfg.mode == PV_MODE_NORMAL_SHIFT || cfg.mode == PV_MODE_GENDER_CHANGE ||
+                                 cfg.mode == PV_MODE_FORMANT_PRESERVE || cfg.mode == PV_MODE_NORMAL_STRETCH ||
+                                 cfg.mode == PV_MODE_FORMANT_CEPSTRAL;
+        // coremode 1 only: the coremode-0 kernel streams whole planes and merely trades places with synthesis
+        // when it runs beside it (measured: 13.42 vs 13.47 Gsamples/s), coremode 2 has no phase kernel
+        return phase_stage && cfg.coremode == 1;
     }
+    bool can_overlap_chain() const { return pipelined_planes; }
 };
 
 int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
@@ -190,7 +197,9 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
         return PV_ERR_UNSUPPORTED;
     }
     Tc = chunk_slices;
-    TR = Tc + 1; // slice-indexed planes keep the last slice of the previous launch (pv_kernels.h)
+    // slice-indexed planes keep the last slice of the previous launch (pv_kernels.h); the pipelined batch path
+    // has two chunks in flight (the front of chunk i+1 runs before the back of chunk i)
+    TR = (nstreams > 0 && pipelined_planes) ? 2 * Tc + 1 : Tc + 1;
     FR = next_pow2_i(Tc + lookback + 1);
 
     // tables
@@ -416,13 +425,32 @@ int Core::build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64
 void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
                         int ntiles, const int64_t *d_P, const float *d_wacc, const float *d_whisper,
                         const InAddr *carrier, float *out, int64_t out_stride_row, int64_t k_base,
-                        hipStream_t st, hipEvent_t *ev, const OlaArgs *prev_ola, OlaArgs *defer,
-                        hipStream_t st_chain, hipEvent_t ev_match, hipEvent_t ev_chain, bool single_launch) const {
+                        hipStream_t st, hipEvent_t *ev, int part, hipStream_t st_chain, hipEvent_t ev_match,
+                        hipEvent_t ev_chain, bool single_launch) const {
+    const bool front = part != 2, back = part != 1;
     StreamArgs fused{};
     const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder;
     const int cm = bypass ? -1 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
     auto rec = [&](int i) {
         if (ev) (void)hipEventRecord(ev[i], st);
+    };
+    // the phase stage's latency-bound kernel: on `st` (part 0), or handed to the second stream after what the
+    // main stream has launched so far (part 1) and waited for before what follows (part 2)
+    auto side_stream = [&](int k, auto &&launch_on) {
+        if (part == 1) {
+            (void)hipEventRecord(ev_match, st);
+            (void)hipStreamWaitEvent(st_chain, ev_match, 0);
+            if (ev) (void)hipEventRecord(ev[2 * k], st_chain);
+            launch_on(st_chain);
+            if (ev) (void)hipEventRecord(ev[2 * k + 1], st_chain);
+            (void)hipEventRecord(ev_chain, st_chain);
+        } else if (part == 2) {
+            (void)hipStreamWaitEvent(st, ev_chain, 0);
+        } else {
+            rec(2 * k);
+            launch_on(st);
+            rec(2 * k + 1);
+        }
     };
     AnalyzeArgs aa{};
     aa.tb = tb;
@@ -440,10 +468,10 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     aa.phase = phase.p;
     aa.peaks = peaks.p;
     aa.npk = npk.p;
-    rec(2 * PV_K_ANALYZE);
+    if (front) rec(2 * PV_K_ANALYZE);
     if (single_launch) fused.aa = aa;
-    else launch_analyze(aa, st);
-    if (d.vocoder && carrier) {
+    else if (front) launch_analyze(aa, st);
+    if (front && d.vocoder && carrier) {
         // the carrier is one more (data-independent) row: same analysis, its own planes
         AnalyzeArgs ca = aa;
         ca.ia = *carrier;
@@ -453,7 +481,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ca.phase = cphase.p;
         launch_analyze(ca, st);
     }
-    rec(2 * PV_K_ANALYZE + 1);
+    if (front) rec(2 * PV_K_ANALYZE + 1);
 
     if (cm == 1) {
         MatchArgs ma{};
@@ -475,10 +503,10 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ma.npk = npk.p;
         ma.recs = recs.p;
         ma.modes = modes.p;
-        rec(2 * PV_K_MATCH);
+        if (front) rec(2 * PV_K_MATCH);
         if (single_launch) fused.ma = ma;
-        else launch_match(ma, st);
-        rec(2 * PV_K_MATCH + 1);
+        else if (front) launch_match(ma, st);
+        if (front) rec(2 * PV_K_MATCH + 1);
         SeqArgs qa{};
         qa.N = d.N;
         qa.hs = d.hs;
@@ -503,28 +531,8 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         qa.st_kind = st_kind.p;
         qa.st_rot = st_rot.p;
         qa.st_po = st_po.p;
-        if (single_launch) {
-            fused.qa = qa;
-        } else if (st_chain && st_chain != st) {
-            // chain on its own stream: after this chunk's match, beside the previous chunk's overlap-add
-            (void)hipEventRecord(ev_match, st);
-            (void)hipStreamWaitEvent(st_chain, ev_match, 0);
-            if (ev) (void)hipEventRecord(ev[2 * PV_K_SEQ], st_chain);
-            launch_seq(qa, st_chain);
-            if (ev) (void)hipEventRecord(ev[2 * PV_K_SEQ + 1], st_chain);
-            (void)hipEventRecord(ev_chain, st_chain);
-            if (prev_ola && prev_ola->ntiles > 0) {
-                rec(2 * PV_K_OLA_RESAMPLE);
-                launch_ola(*prev_ola, st);
-                rec(2 * PV_K_OLA_RESAMPLE + 1);
-            }
-            (void)hipStreamWaitEvent(st, ev_chain, 0);
-        } else {
-            if (prev_ola && prev_ola->ntiles > 0) launch_ola(*prev_ola, st);
-            rec(2 * PV_K_SEQ);
-            launch_seq(qa, st);
-            rec(2 * PV_K_SEQ + 1);
-        }
+        if (single_launch) fused.qa = qa;
+        else side_stream(PV_K_SEQ, [&](hipStream_t s) { launch_seq(qa, s); });
     } else if (cm == 0) {
         PropArgs pa{};
         pa.N = d.N;
@@ -543,10 +551,8 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         pa.outphase = outphase.p;
         pa.st_pp = st_pp.p;
         pa.st_po = st_po.p;
-        rec(2 * PV_K_PROP);
         if (single_launch) fused.pa = pa;
-        else launch_prop(pa, st);
-        rec(2 * PV_K_PROP + 1);
+        else side_stream(PV_K_PROP, [&](hipStream_t s) { launch_prop(pa, s); });
     }
 
     SynthArgs sa{};
@@ -591,15 +597,15 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ca.env_comp = d.env_comp;
         ca.inv_n = d.inv_n;
         ca.mag = mag.p;
-        rec(2 * PV_K_CEPSTRAL);
+        if (back) rec(2 * PV_K_CEPSTRAL);
         if (single_launch) fused.ca = ca;
-        else launch_cepstral(ca, st);
-        rec(2 * PV_K_CEPSTRAL + 1);
+        else if (back) launch_cepstral(ca, st);
+        if (back) rec(2 * PV_K_CEPSTRAL + 1);
     }
-    rec(2 * PV_K_SYNTH);
+    if (back) rec(2 * PV_K_SYNTH);
     if (single_launch) fused.sa = sa;
-    else launch_synth(sa, st);
-    rec(2 * PV_K_SYNTH + 1);
+    else if (back) launch_synth(sa, st);
+    if (back) rec(2 * PV_K_SYNTH + 1);
 
     OlaArgs oa{};
     oa.N = d.N;
@@ -633,9 +639,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         fused.coremode = cm;
         fused.cepstral = d.cepstral ? 1 : 0;
         launch_stream(fused, st);
-    } else if (defer) {
-        *defer = oa; // launched later, beside the next chunk's chain
-    } else if (ntiles > 0) {
+    } else if (back && ntiles > 0) {
         rec(2 * PV_K_OLA_RESAMPLE);
         launch_ola(oa, st);
         rec(2 * PV_K_OLA_RESAMPLE + 1);
@@ -800,6 +804,7 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
         const int v = atoi(env);
         if (v >= 4 && v <= 1024) Tc = v;
     }
+    b->core.pipelined_planes = Core::pipeline_wanted(*cfg);
     int st = b->core.init(*cfg, device, nstreams, Tc);
     if (st != PV_OK) return st;
     Core &c = b->core;
@@ -873,6 +878,7 @@ void pv_batch_destroy(pv_batch *b) { delete b; }
 int64_t pv_batch_out_frames(const pv_batch *b) { return b ? b->plan.out_frames : -1; }
 int64_t pv_batch_slices(const pv_batch *b) { return b ? (int64_t)b->plan.slices.size() : -1; }
 int32_t pv_batch_launches(const pv_batch *b) { return b ? (int32_t)b->chunks.size() : -1; }
+int32_t pv_batch_pipelined(const pv_batch *b) { return b ? (b->chain_stream != nullptr ? 1 : 0) : -1; }
 
 int pv_batch_get_info(const pv_batch *b, pv_info *info) {
     if (!b || !info) return PV_ERR_INVALID_ARG;
@@ -913,36 +919,45 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
     car.stride_s = 0;
     car.mask = ~0ull;
     car.len = (int64_t)b->d_carrier.n;
-    // Software pipeline of the phase-locked path: the overlap-add of chunk i-1 is launched after the match of
-    // chunk i, so it runs while the second stream walks chunk i's rotation chain; the last chunk's overlap-add
-    // follows the loop.
-    const bool fused = b->chain_stream != nullptr;
-    OlaArgs pending{}, next_pending{};
-    pending.rows = c.rows;
-    size_t ci = 0;
-    for (const auto &ch : b->chunks) {
-        hipEvent_t *ev = nullptr;
-        if (b->timing > 0 && (int)(ci % (size_t)b->timing) == (b->timing / 2) % b->timing) {
-            const size_t need = b->ev_used + kEvPerChunk;
-            while (b->ev_pool.size() < need) {
-                hipEvent_t e;
-                HIPC(hipEventCreate(&e));
-                b->ev_pool.push_back(e);
-            }
-            ev = &b->ev_pool[b->ev_used];
-            b->ev_used = need;
-            b->ev_chunk.push_back((int)ci);
+    // Software pipeline of the phase-locked path (two chunks in flight): the main stream runs the front of chunk i
+    // (analysis, match), then the back of chunk i-1 (synthesis, overlap-add); the second stream walks chunk i's
+    // rotation chain meanwhile, and has until the back of chunk i -- one more front later -- to finish.
+    const bool piped = b->chain_stream != nullptr;
+    auto events_for = [&](size_t ci) -> hipEvent_t * {
+        if (!(b->timing > 0 && (int)(ci % (size_t)b->timing) == (b->timing / 2) % b->timing)) return nullptr;
+        const size_t need = b->ev_used + kEvPerChunk;
+        while (b->ev_pool.size() < need) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            b->ev_pool.push_back(e);
         }
+        hipEvent_t *ev = &b->ev_pool[b->ev_used];
+        b->ev_used = need;
+        b->ev_chunk.push_back((int)ci);
+        return ev;
+    };
+    auto launch = [&](size_t ci, hipEvent_t *ev, int part) {
+        const auto &ch = b->chunks[ci];
         c.launch_chunk(ia, ch.t0, ch.Tn, b->d_pinc.p + ch.t0, b->d_tiles.p + ch.tile_begin, ch.ntiles, b->d_P.p,
                        b->d_wacc.p + (size_t)ch.tile_begin * c.wacc_pitch,
                        b->d_whisper.p ? b->d_whisper.p + (size_t)ch.t0 * c.C * c.HP : nullptr,
-                       c.d.vocoder ? &car : nullptr, d_out, b->plan.out_frames, 0, st, ev,
-                       fused ? &pending : nullptr, fused ? &next_pending : nullptr, b->chain_stream,
+                       c.d.vocoder ? &car : nullptr, d_out, b->plan.out_frames, 0, st, ev, part, b->chain_stream,
                        b->ev_match[ci & 3], b->ev_chain[ci & 3]);
-        if (fused) pending = next_pending;
-        ++ci;
+    };
+    const size_t nchunks = b->chunks.size();
+    if (piped) {
+        // the chain stream must not start before the caller's stream has reached this run (state reset, inputs)
+        hipEvent_t *prev_ev = nullptr;
+        for (size_t ci = 0; ci < nchunks; ++ci) {
+            hipEvent_t *ev = events_for(ci);
+            launch(ci, ev, 1);
+            if (ci > 0) launch(ci - 1, prev_ev, 2);
+            prev_ev = ev;
+        }
+        if (nchunks > 0) launch(nchunks - 1, prev_ev, 2);
+    } else {
+        for (size_t ci = 0; ci < nchunks; ++ci) launch(ci, events_for(ci), 0);
     }
-    if (fused && pending.ntiles > 0) launch_ola(pending, st);
     HIPC(hipGetLastError());
     return PV_OK;
 }
@@ -959,9 +974,8 @@ int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launch
             if (k == PV_K_PROP && cm != 0) continue;
             if (k == PV_K_CEPSTRAL && !d.cepstral) continue;
             if (k == PV_K_OLA_RESAMPLE) {
-                // with the chain on its own stream the OLA events of chunk i bracket chunk i-1's overlap-add
-                const int ci2 = b->ev_chunk[i / kEvPerChunk] - (b->chain_stream ? 1 : 0);
-                if (ci2 < 0 || b->chunks[(size_t)ci2].ntiles == 0) continue;
+                const int ci2 = b->ev_chunk[i / kEvPerChunk];
+                if (b->chunks[(size_t)ci2].ntiles == 0) continue;
             }
             float t = 0;
             if (hipEventElapsedTime(&t, b->ev_pool[i + 2 * k], b->ev_pool[i + 2 * k + 1]) == hipSuccess) {
@@ -1134,8 +1148,8 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
                        reinterpret_cast<const OlaTile *>(e->d_desc.p + t_off_bytes), (int)tiles.size(),
                        reinterpret_cast<const int64_t *>(e->d_desc.p + p_off_bytes),
                        reinterpret_cast<const float *>(e->d_desc.p + w_off_bytes), e->d_whisper.p,
-                       c.d.vocoder ? &car : nullptr, e->d_out.p, e->out_cap, ka, e->stream, nullptr, nullptr, nullptr,
-                       nullptr, nullptr, nullptr, c.can_single_launch());
+                       c.d.vocoder ? &car : nullptr, e->d_out.p, e->out_cap, ka, e->stream, nullptr, 0, nullptr, nullptr,
+                       nullptr, c.can_single_launch());
         (void)p_off_bytes;
         const int64_t cnt = kb - ka;
         if (cnt > 0)

@@ -95,6 +95,8 @@ def lib():
     L.pv_batch_slices.restype = C.c_int64
     L.pv_batch_launches.argtypes = [C.c_void_p]
     L.pv_batch_launches.restype = C.c_int32
+    L.pv_batch_pipelined.argtypes = [C.c_void_p]
+    L.pv_batch_pipelined.restype = C.c_int32
     L.pv_batch_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
     L.pv_batch_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pv_batch_enable_timing.argtypes = [C.c_void_p, C.c_int]
@@ -275,6 +277,7 @@ class Batch:
         self.out_frames = self.L.pv_batch_out_frames(self.h)
         self.slices = self.L.pv_batch_slices(self.h)
         self.launches = self.L.pv_batch_launches(self.h)
+        self.pipelined = bool(self.L.pv_batch_pipelined(self.h))  # chain kernel on a second stream (overlapped)
 
     def close(self):
         if getattr(self, "h", None):

@@ -251,9 +251,16 @@ def main():
             avg_ms = sum(per_kernel[k]["avg_ms"] for k in live)
             per_stage[name] = {"kernels": live, "avg_ms": round(avg_ms, 4), "bytes_per_slice": nbytes,
                                "GBps": round(nbytes * slices_per_launch / (avg_ms * 1e-3) / 1e9, 1)}
-        dom_stage = max(per_stage, key=lambda k: per_stage[k]["avg_ms"])
-        dom = max(per_stage[dom_stage]["kernels"], key=lambda k: per_kernel[k]["avg_ms"])
-        achieved = per_stage[dom_stage]["GBps"]
+        # With the pipelined batch path the phase stage's sequential kernel runs on a second HIP stream beside the others:
+        # its duration is not on the critical path, so the roofline entry is the longest kernel of the MAIN stream
+        # (a stage's GB/s is still computed over all of its kernels' durations).
+        overlapped = [k for k in ("pv_seq_kernel", "pv_prop_kernel") if batch.pipelined and k in per_kernel]
+        main = {k: v for k, v in per_kernel.items() if k not in overlapped}
+        dom = max(main, key=lambda k: main[k]["avg_ms"])
+        dom_stage = next(n for n, (_, ks) in stages.items() if dom in ks)
+        dom_bytes = stages[dom_stage][0]
+        achieved = round(dom_bytes * slices_per_launch / (main[dom]["avg_ms"] * 1e-3) / 1e9, 1) \
+            if dom_stage != "phase" or not overlapped else per_stage[dom_stage]["GBps"]
         traffic = traffic_db.get(dom) if (G == 1 and args.streams == 128 and args.config == "cfg2") else None
         pipeline_gbps = info["bytes_per_slice"] * slices_per_step_gpu * args.steps / dt / 1e9
         copy_gbps = copy_ceiling_gbps(torch, device)
@@ -272,7 +279,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "copy_ceiling_GBps": round(copy_gbps, 1), "frac_of_copy_ceiling": round(achieved / copy_gbps, 4),
                          "stage": dom_stage, "slices_per_launch": round(slices_per_launch, 1),
-                         "pipeline_GBps": round(pipeline_gbps, 1), "per_stage": per_stage,
+                         "pipeline_GBps": round(pipeline_gbps, 1), "overlapped_on_second_stream": overlapped,
+                         "per_stage": per_stage,
                          "per_kernel": per_kernel},
         }
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":

@@ -134,6 +134,10 @@ void pv_batch_destroy(pv_batch *b);
 int64_t pv_batch_out_frames(const pv_batch *b);
 int64_t pv_batch_slices(const pv_batch *b); /* slices per channel per stream */
 int32_t pv_batch_launches(const pv_batch *b); /* launches of each kernel per pv_batch_run (= chunks of slices) */
+/* 1 when pv_batch_run software-pipelines the phase-locked path: the rotation chain (PV_K_SEQ) of chunk i then runs on a
+ * second HIP stream beside the synthesis / overlap-add of chunk i-1 and the analysis / match of chunk i+1, so its
+ * measured duration overlaps the other kernels' (environment AUDIOMOD_PV_PIPELINE=0 turns it off) */
+int32_t pv_batch_pipelined(const pv_batch *b);
 int pv_batch_get_info(const pv_batch *b, pv_info *info);
 int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream);
 /* Optional per-kernel timing of the NEXT pv_batch_run calls (HIP events on the run's stream).
