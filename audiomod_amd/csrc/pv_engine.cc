@@ -153,7 +153,9 @@ struct Core {
                                  cfg.mode == PV_MODE_FORMANT_CEPSTRAL;
         // coremode 1 only: the coremode-0 kernel streams whole planes and merely trades places with synthesis
         // when it runs beside it (measured: 13.42 vs 13.47 Gsamples/s), coremode 2 has no phase kernel
-        return phase_stage && cfg.coremode == 1;
+        // ... and frames up to 2048 points: at 4096 the synthesis waves hold 240 VGPRs, two to a SIMD, and lose
+        // more to the chain's waves beside them than the overlap returns (measured: 9.65 vs 9.77 Gsamples/s)
+        return phase_stage && cfg.coremode == 1 && cfg.fftsize <= 2048;
     }
     bool can_overlap_chain() const { return pipelined_planes; }
 };
