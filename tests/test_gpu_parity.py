@@ -262,6 +262,35 @@ def test_batch_rows_at_unaligned_offsets(frames):
         assert rms(out[s], want) <= RMS_TOL
 
 
+def test_pipelined_batch_path_is_bit_identical_to_the_plain_one():
+    """pv_batch_run keeps two chunks in flight in phase-locked mode (rotation chain on a second stream); with
+    AUDIOMOD_PV_PIPELINE=0 it runs chunk after chunk on one stream.  Same kernels, same data: identical bits.
+    Small chunks so that many of them are in the pipeline."""
+    import hashlib
+    import subprocess
+    import sys
+    code = """
+import hashlib, numpy as np, sys, torch
+sys.path.insert(0, %r)
+from audiomod_amd import engine as E, signals
+x = np.stack([signals.voice(60000, 2, seed=70 + s) for s in range(3)])
+b = E.Batch(3, 60000, channels=2, semitones=4.0)
+out = b.run(torch.from_numpy(x).cuda())
+torch.cuda.synchronize()
+print("PIPELINED", int(b.pipelined), "LAUNCHES", b.launches, "SHA", hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest())
+""" % (ROOT,)
+    res = {}
+    for pipe in ("1", "0"):
+        env = dict(os.environ, AUDIOMOD_PV_PIPELINE=pipe, AUDIOMOD_PV_CHUNK_SLICES="8")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        f = r.stdout.split()
+        res[pipe] = (int(f[1]), int(f[3]), f[5])
+    assert res["1"][0] == 1 and res["0"][0] == 0
+    assert res["1"][1] == res["0"][1] and res["1"][1] > 10
+    assert res["1"][2] == res["0"][2]
+
+
 def test_single_launch_streaming_kernel():
     """The opt-in one-launch-per-call kernel of the streaming path (AUDIOMOD_PV_STREAM_LAUNCHES=single; read once
     per process, hence the child process) must give the same results as one launch per stage."""
