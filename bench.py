@@ -97,10 +97,44 @@ def cpu_baseline(seconds=480, all_cores_seconds=240):
         t0 = time.perf_counter()
         O.run_offline(x, **kw)
         dt = time.perf_counter() - t0
+    fast = native_port_speed(min(seconds, 240))
+    if fast:
+        res["native_port"] = fast
     res.update({"value": round(frames * 2 / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": kind,
                 "x_realtime": round(seconds / dt, 2),
                 "sample": f"1 stereo stream x {seconds} s, same config, block 480, wall {dt:.2f} s"})
     return res
+
+
+def native_port_speed(seconds):
+    """SURVEY 8(d)'s fair-speed figure: this repository's own CPU port (oracle/pv_oracle.c) rebuilt for the host it
+    runs on (-O3 -march=native: vector units and FMA allowed, so its output is no longer bit-identical -- a speed
+    figure only), one stereo stream on one core.  None when there is no compiler."""
+    import shutil
+    if shutil.which("gcc") is None:
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            so = os.path.join(d, "libpv_oracle_native.so")
+            subprocess.run(["gcc", "-O3", "-march=native", "-std=gnu99", "-fPIC", "-shared",
+                            os.path.join(ROOT, "oracle", "pv_oracle.c"), "-o", so, "-lm"], check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            code = ("import sys, time, numpy as np\n"
+                    f"sys.path.insert(0, {ROOT!r})\n"
+                    "from oracle import oracle_py as O\n"
+                    "from audiomod_amd import signals\n"
+                    f"O.LIB_PATH = {so!r}\n"
+                    f"x = np.tile(signals.voice(10 * 48000, 2), (1, {(seconds + 9) // 10}))[:, :{seconds * 48000}]\n"
+                    "t0 = time.perf_counter()\n"
+                    "O.run_offline(x, mode='normal_pitchshift', semitones=4.0, coremode=1, fftsize=2048)\n"
+                    "print(time.perf_counter() - t0)\n")
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+            dt = float(r.stdout.strip().splitlines()[-1])
+        return {"value": round(seconds * 48000 * 2 / dt / 1e6, 4), "x_realtime": round(seconds / dt, 2), "cores": 1,
+                "kind": "port", "flags": "-O3 -march=native",
+                "sample": f"1 stereo stream x {seconds} s, wall {dt:.2f} s (480-frame calls from Python)"}
+    except Exception:  # a figure for context only: never let it break the bench line
+        return None
 
 
 def usable_cores(cap=16):
