@@ -749,7 +749,7 @@ const char *pv_strerror(int s) {
     }
 }
 
-const char *pv_last_error(void) { return g_last_error.c_str(); }
+const char *pv_last_error(void) { return g_last_error.empty() ? plan_reason() : g_last_error.c_str(); }
 
 int pv_device_count(void) { return count_gfx950(); }
 
@@ -762,6 +762,8 @@ const char *pv_kernel_name(int k) {
 
 int pv_plan_simulate(const pv_config *cfg, const int32_t *n, int32_t ncalls, int32_t *avail, int32_t *shift,
                      int32_t *phase, int64_t max_slices, int64_t *nslices, pv_info *info) {
+    g_last_error.clear();
+    plan_reason_clear();
     if (!cfg || (ncalls > 0 && !n)) return PV_ERR_INVALID_ARG;
     Derived d;
     int st = derive(*cfg, d);
@@ -793,6 +795,8 @@ int pv_plan_whisper_phases(int64_t n, float *out) {
 // ---------------------------------------------------------------- batch
 int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int32_t block, int32_t flush, int device,
                     pv_batch **out) {
+    g_last_error.clear();
+    plan_reason_clear();
     if (!cfg || !out || nstreams < 1 || frames < 1 || block < 1) return PV_ERR_INVALID_ARG;
     *out = nullptr;
     std::unique_ptr<pv_batch> b(new pv_batch());
@@ -901,7 +905,9 @@ int pv_batch_enable_timing(pv_batch *b, int on) {
 }
 
 int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream) {
-    if (!b || !d_in || !d_out) return PV_ERR_INVALID_ARG;
+    g_last_error.clear();
+    plan_reason_clear();
+    if (!b || !d_in || (!d_out && b->plan.out_frames > 0)) return PV_ERR_INVALID_ARG; // an empty output needs no buffer
     Core &c = b->core;
     hipStream_t st = (hipStream_t)hip_stream;
     HIPC(hipSetDevice(c.device));
@@ -999,6 +1005,8 @@ int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launch
 static constexpr int kStreamChunk = 16; // slices per launch group in streaming mode
 
 int pv_create(const pv_config *cfg, int device, pv_engine **out) {
+    g_last_error.clear();
+    plan_reason_clear();
     if (!cfg || !out) return PV_ERR_INVALID_ARG;
     *out = nullptr;
     std::unique_ptr<pv_engine> e(new pv_engine());
@@ -1071,6 +1079,8 @@ static int upload_until(pv_engine *e, const float *const *in, int64_t call_base,
 }
 
 int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
+    g_last_error.clear();
+    plan_reason_clear();
     if (!e || n < 0 || (n > 0 && !in)) return PV_ERR_INVALID_ARG;
     Core &c = e->core;
     HIPC(hipSetDevice(c.device));

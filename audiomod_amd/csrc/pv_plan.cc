@@ -326,6 +326,10 @@ int Planner::next_increment() {
     return incr;
 }
 
+static thread_local const char *g_plan_reason = "";
+const char *plan_reason() { return g_plan_reason; }
+void plan_reason_clear() { g_plan_reason = ""; }
+
 int Planner::try_slice(std::vector<SliceRec> &out) {
     if (in_fill_ < d_.N) return PV_OK; // inbufReady false -> processOneSlice returns early
     in_fill_ -= d_.hop;
@@ -340,7 +344,13 @@ int Planner::try_slice(std::vector<SliceRec> &out) {
         phaseInc = prev_increment_ == 0 ? shiftInc : (size_t)prev_increment_;
         prev_increment_ = (int64_t)shiftInc;
     }
-    if ((int64_t)shiftInc < 1 || (int64_t)shiftInc > d_.N) return PV_ERR_UNSUPPORTED;
+    if ((int64_t)shiftInc < 1 || (int64_t)shiftInc > d_.N) {
+        // writeSlice (phasevocoderprocess.cc:1181-1190) moves N - shiftIncrement floats: beyond N that count wraps
+        // and the reference overruns its accumulators -- undefined there, refused here
+        g_plan_reason = "a slice's shift increment falls outside [1, fftsize] (hop too large for this ratio): "
+                        "undefined behaviour in the reference";
+        return PV_ERR_UNSUPPORTED;
+    }
     SliceRec r;
     r.shift = (int32_t)shiftInc;
     r.phase_inc = (int32_t)phaseInc;
@@ -363,7 +373,10 @@ int Planner::try_slice(std::vector<SliceRec> &out) {
     // output-ring guard (phasevocoderprocess.cc:337-364)
     int required = (d_.constant || d_.vocoder) ? d_.hop : int(shiftInc / d_.pitch_scale) + 1; // :142, :1203 vs :337
     int64_t ws = d_.outbuf_cap - out_fill_;
-    if (ws < required) return PV_ERR_OUTPUT_OVERRUN;
+    if (ws < required) {
+        g_plan_reason = "more output pending than the reference's output ring holds: retrieve between calls";
+        return PV_ERR_OUTPUT_OVERRUN;
+    }
     out_fill_ += r.cnt;
     P_ = Pn;
     K_ = Kn;

@@ -79,6 +79,11 @@ struct SliceRec {
 };
 
 // Integer simulation of the reference's ring occupancy and increment recurrences.
+// why the planner last refused something (thread-local static text, "" if it has not); cleared by the C-ABI entry
+// points and folded into pv_last_error()
+const char *plan_reason();
+void plan_reason_clear();
+
 class Planner {
   public:
     explicit Planner(const Derived &d) : d_(d) {}

@@ -78,6 +78,10 @@ def _pp(arrs):
     return (fp * len(arrs))(*[a.ctypes.data_as(fp) for a in arrs])
 
 
+class OracleUndefined(RuntimeError):
+    """The configuration drives the reference into undefined behaviour (pv_oracle.h PVO_UNDEFINED)."""
+
+
 class Oracle:
     """Streaming handle mirroring audiomod::phasevocoder's offline + real-time drive."""
 
@@ -106,7 +110,10 @@ class Oracle:
         block = np.ascontiguousarray(block, dtype=np.float32)
         assert block.shape[0] == self.channels
         rows = [block[c] for c in range(self.channels)]
-        return self.L.pvo_process(self.h, _pp(rows), block.shape[1])
+        got = self.L.pvo_process(self.h, _pp(rows), block.shape[1])
+        if got == -2:  # PVO_UNDEFINED
+            raise OracleUndefined("shift increment above the FFT size: the reference's behaviour is undefined here")
+        return got
 
     def available(self):
         return self.L.pvo_available(self.h)

@@ -634,6 +634,10 @@ struct pvo {
     float *resamplebuf; size_t resamplebuf_size;
     /* record of increments for planner pinning */
     int *rec_shift, *rec_phase; long nrec, caprec;
+    /* set once a slice's shift increment exceeds N: writeSlice (phasevocoderprocess.cc:1181-1190) then calls
+     * memmove with (N - shiftIncrement) wrapped to a huge size_t -- undefined behaviour in the reference, only
+     * reachable with a caller-chosen hop.  The oracle stops there instead of reproducing the overflow. */
+    int undefined;
 };
 
 static float hs_ratio(const pvo *h) { return h->time_ratio * h->pitch_scale; }
@@ -1008,6 +1012,10 @@ static void synthesise(pvo *h, chan *a) {
 static int write_slice(pvo *h, chan *a, size_t shiftIncrement) {
     const int N = (int)h->N;
     const int s = (int)shiftIncrement;
+    if (s > N) {
+        h->undefined = 1;
+        return 0;
+    }
     for (int i = 0; i < s; ++i) a->oacc[i] /= a->wacc[i];
     int outframes;
     if (h->pitch_scale != 1.0) {
@@ -1240,6 +1248,7 @@ int pvo_process(pvo *h, const float *const *in, int n) {
         else process_one_slice(h);
     }
     free(nread);
+    if (h->undefined) return PVO_UNDEFINED;
     return pvo_available(h);
 }
 

@@ -50,7 +50,10 @@ typedef struct pvo pvo;
 
 pvo *pvo_create(const pvo_config *cfg);
 void pvo_destroy(pvo *h);
-/* == phasevocodercore::Impl::processNormal (phasevocoderimpl.cc:340-369); returns numsamples_available() */
+/* == phasevocodercore::Impl::processNormal (phasevocoderimpl.cc:340-369); returns numsamples_available(), or
+ * PVO_UNDEFINED once a slice's shift increment exceeded the FFT size (the reference's writeSlice then overflows
+ * its accumulators: undefined behaviour, reachable only with a caller-chosen hop -- nothing to be on par with) */
+#define PVO_UNDEFINED (-2)
 int pvo_process(pvo *h, const float *const *in, int n);
 int pvo_available(const pvo *h);
 /* == Impl::retrieve (phasevocoderprocess.cc:1266-1284); returns frames read per channel */
