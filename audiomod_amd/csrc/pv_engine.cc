@@ -369,6 +369,10 @@ int Core::build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64
         while (t_lo < t_end && slices[(size_t)(t_lo - t_base)].P + d.N <= n0) ++t_lo;
         if (t_hi < t_lo) t_hi = t_lo;
         while (t_hi + 1 < t_end && slices[(size_t)(t_hi + 1 - t_base)].P <= n_hi) ++t_hi;
+        if (t_lo > t_base && t_lo == t_end - FR && slices[(size_t)(t_lo - 1 - t_base)].P + d.N > n0) {
+            g_last_error = "internal: OLA tile needs a frame the ring no longer holds";
+            return PV_ERR_UNSUPPORTED;
+        }
         if (t_lo >= t_end) {
             g_last_error = "internal: OLA tile has no covering slice";
             return PV_ERR_UNSUPPORTED;
@@ -1020,8 +1024,11 @@ int pv_create(const pv_config *cfg, int device, pv_engine **out) {
     HIPC(hipMemset(e->d_in.p, 0, e->d_in.n * sizeof(float)));
     if ((st = e->h_in.alloc((size_t)c.C * e->ring)) != PV_OK) return st;
     // most outputs one group of slices can emit
-    const double per_slice = c.d.resample ? (2.0 * c.d.hop * c.d.hs_ratio) * c.d.res_den / c.d.res_num + 2
-                                          : 2.0 * c.d.hop * c.d.hs_ratio + 2;
+    // (largest shift increment -- the hop itself in the modes that do not stretch, else the upper clamp
+    // lrint(2 * hop * ratio), phasevocoderprocess.cc:394-395 -- through the resampler where there is one)
+    const bool fixed_shift = c.d.robotic || c.d.whisper || c.d.constant || c.d.vocoder;
+    const double max_shift = fixed_shift ? (double)c.d.hop : 2.0 * c.d.hop * c.d.hs_ratio + 1;
+    const double per_slice = c.d.resample ? max_shift * c.d.res_den / c.d.res_num + 2 : max_shift + 2;
     e->out_cap = (int)(kStreamChunk * per_slice) + 64;
     if ((st = e->d_out.alloc((size_t)c.C * e->out_cap)) != PV_OK) return st;
     if ((st = e->h_out.alloc((size_t)c.C * e->out_cap)) != PV_OK) return st;

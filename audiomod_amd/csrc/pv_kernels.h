@@ -10,7 +10,8 @@ namespace pv {
 
 constexpr int kFftThreads = 256;   // workgroup size of the analysis / synthesis kernels (4 waves)
 constexpr int kTileOut = 256;      // outputs (= threads) per workgroup of the OLA+resample kernel
-constexpr int kMaxTileFrames = 64; // frames that can overlap one OLA tile (checked on the host)
+constexpr int kMaxTileFrames = 128; // frames that can overlap one OLA tile (checked on the host; the small FFT
+                                    // sizes with a large pitch scale reach ~70 at the automatic hop)
 
 struct DevTables {
     int N, hs, H, HP, nc, log2nc;

@@ -374,6 +374,10 @@ int Planner::try_slice(std::vector<SliceRec> &out) {
     int required = (d_.constant || d_.vocoder) ? d_.hop : int(shiftInc / d_.pitch_scale) + 1; // :142, :1203 vs :337
     int64_t ws = d_.outbuf_cap - out_fill_;
     if (ws < required) {
+        // The reference drops the slice here (processSliceForChannel :337-364: frame already added into the
+        // accumulators, writeSlice skipped, so the following frames pile up on the same overlap-add position; the
+        // CONSTANT / vocoder loops even leave the channels in different states).  A run of dropped slices is
+        // unbounded, the frame ring is not: refused, loudly, instead of reproduced.
         g_plan_reason = "more output pending than the reference's output ring holds: retrieve between calls";
         return PV_ERR_OUTPUT_OVERRUN;
     }

@@ -421,6 +421,55 @@ def test_formant_cepstral_needs_a_wave_fft_size():
         E.PhaseVocoder(48000, 2, 1.0, 4.0, E.FORMANT_CEPSTRAL, 1, 1024)
 
 
+# Configurations the randomised sweep (tools/fuzz_parity.py) turned up as refused or wrong at some point.
+SWEEP_FINDS = [
+    # per-call output above the streaming staging buffer: fixed-hop modes through a > 2x up-sampling resampler
+    (dict(mode="robotic", fftsize=1024, sample_rate=16000, semitones=-15.8), 2, 887, 4724, True),
+    (dict(mode="constant", fftsize=512, semitones=-14.53), 3, 5105, 1650, True),
+    (dict(mode="vocoder_chord", fftsize=1024, semitones=-13.0), 2, 12000, 4800, True),
+    # many frames under one overlap-add tile: small FFT, large pitch scale / small ratio, automatic hop
+    (dict(fftsize=256, semitones=15.558), 2, 20000, 480, True),
+    (dict(mode="time_stretch", fftsize=256, time_ratio=0.374, coremode=0, sample_rate=96000), 1, 9000, 64, False),
+    (dict(mode="constant", fftsize=256, semitones=14.65, sample_rate=16000), 3, 4000, 480, True),
+    # the reference's Rosenberg carrier is NaN below ~22 kHz (zero-length opening phase, rosenberg.cc:19-53)
+    (dict(mode="vocoder", fftsize=2048, sample_rate=16000, semitones=-6.0), 2, 6000, 480, True),
+    (dict(mode="vocoder_chord", fftsize=512, sample_rate=22050, semitones=8.0), 2, 9000, 4800, True),
+]
+
+
+@pytest.mark.parametrize("kw,ch,frames,block,flush", SWEEP_FINDS, ids=[str(i) for i in range(len(SWEEP_FINDS))])
+def test_sweep_finds(kw, ch, frames, block, flush):
+    import torch
+    x = signals.voice(frames, ch, seed=31)
+    want, wc, _ = O.run_offline(x, block=block, flush=flush, **kw)
+    got, gc = E.run_offline(x, block=block, flush=flush, **kw)
+    assert list(gc) == list(wc) and got.shape == want.shape
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)  # non-finite exactly where the reference is
+    assert rms(got[fin], want[fin]) <= RMS_TOL if fin.any() else True
+    b = E.Batch(2, frames, channels=ch, block=block, flush=flush, **kw)
+    out = b.run(torch.from_numpy(np.stack([x, x])).cuda())
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    b.close()
+    assert out.shape[2] == want.shape[1]
+    for s_ in range(2):
+        assert np.array_equal(np.isfinite(out[s_]), fin)
+        assert rms(out[s_][fin], want[fin]) <= RMS_TOL if fin.any() else True
+
+
+def test_batch_with_no_output_at_all():
+    """Shorter than one FFT frame and no flush (the time_stretch rule, main.cc:471-478): zero output frames is a
+    valid job, not an argument error."""
+    import torch
+    b = E.Batch(2, 1482, channels=2, flush=False, semitones=7.04, fftsize=8192)
+    assert b.out_frames == 0
+    out = b.run(torch.zeros(2, 2, 1482, device="cuda"))
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (2, 2, 0)
+    b.close()
+
+
 def test_invalid_modes_fail_loudly():
     for mode in (9, 42, -2):
         with pytest.raises(E.PvError):

@@ -106,8 +106,11 @@ def test_errors():
         E.plan_simulate([480], channels=0, semitones=4.0)
     with pytest.raises(E.PvError):
         E.plan_simulate([480], channels=2, mode=42)
-    with pytest.raises(E.PvError):  # output never retrieved: the reference's ring would overrun
+    # output never retrieved: the reference's ring overruns and it starts dropping slices; refused with a reason
+    with pytest.raises(E.PvError, match="output ring overrun.*retrieve between calls"):
         E.plan_simulate([100000], channels=2, semitones=-3.0)
+    with pytest.raises(E.PvError, match="output ring overrun"):
+        E.plan_simulate([4800], channels=2, mode="constant", fftsize=256)
 
 
 def test_output_hop_above_the_fft_size_is_refused_on_both_sides():
