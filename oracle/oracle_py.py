@@ -163,6 +163,10 @@ def run_realtime(x, block=480, **kw):
     """The reference's processBlock/outputReady loop (main/main.cc:561-572) on the oracle."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     ch, frames = x.shape
+    if kw.get("mode") in ("time_stretch", MODES["time_stretch"]):
+        # processBlock dispatches on the mode and has no branch for NORMAL_STRETCH (phasevocoder.cc:126-152):
+        # nothing is processed, the caller's buffer stays as it was and outputReady() is true
+        return x.copy(), [min(block, frames - i) for i in range(0, frames, block)]
     o = Oracle(ch, **kw)
     outs, counts = [], []
     for i in range(0, frames, block):

@@ -458,6 +458,15 @@ def test_sweep_finds(kw, ch, frames, block, flush):
         assert rms(out[s_][fin], want[fin]) <= RMS_TOL if fin.any() else True
 
 
+def test_process_block_ignores_time_stretch():
+    """processBlock has no branch for NORMAL_STRETCH (phasevocoder.cc:126-152): buffer untouched, always ready."""
+    x = signals.voice(5000, 2, seed=5)
+    got, cnt = E.run_realtime(x, block=480, mode="time_stretch", time_ratio=1.5)
+    want, wc = O.run_realtime(x, block=480, mode="time_stretch", time_ratio=1.5)
+    assert cnt == wc == [480] * 10 + [200]
+    assert bits_equal(got, x) and bits_equal(want, x)
+
+
 def test_batch_with_no_output_at_all():
     """Shorter than one FFT frame and no flush (the time_stretch rule, main.cc:471-478): zero output frames is a
     valid job, not an argument error."""
