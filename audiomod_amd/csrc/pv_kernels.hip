@@ -1643,15 +1643,21 @@ void launch_cepstral(const CepstralArgs &a, hipStream_t st) {
 // --------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void ola_role(const OlaArgs &a, const int tile_i, const int row, char *smem_raw) {
+// NR rows (stream-channels) per workgroup.  All rows share one schedule, so a tile's descriptor, its frame
+// offsets, its output table and -- in the resampler -- the coefficient row of an output are the same for every row:
+// with NR = 2 a workgroup fetches them once for two rows, each resampler thread reads a coefficient once for two
+// outputs (the loop is bound by LDS reads), and the dependent chain descriptor -> offsets -> frame gather ->
+// resample, which at full occupancy is what the kernel waits on, is paid once for twice the work.
+template <int NR>
+__device__ __forceinline__ void ola_role(const OlaArgs &a, const int tile_i, const int row0, char *smem_raw) {
     // interpolated mode: coefficient table expanded per sub-sample offset, tab4[off][j] = the four taps
     // sinc[4 + (j+1)*ov - off + {-2,-1,0,1}] of resampler_basic_interpolate_single (resample.c:494-535) as one
     // aligned float4; rows are padded to NF+1 slots so the (at most ov) distinct rows a wave reads in one
     // ds_read_b128 land on different banks.  direct mode: the sinc table as it is.
     float4 *tab4 = reinterpret_cast<float4 *>(smem_raw);
     float *stab = reinterpret_cast<float *>(smem_raw);
-    float *ola = reinterpret_cast<float *>(smem_raw + a.tab_bytes);   // [lds_floats]
-    int *sP = reinterpret_cast<int *>(ola + a.lds_floats);            // [kMaxTileFrames] P_t - n_lo
+    float *ola = reinterpret_cast<float *>(smem_raw + a.tab_bytes);   // [NR][lds_floats]
+    int *sP = reinterpret_cast<int *>(ola + NR * a.lds_floats);       // [kMaxTileFrames] P_t - n_lo
     const int nt = blockDim.x, tid = threadIdx.x;
     const OlaTile tile = a.tiles[tile_i];
     const int N = a.N, NF = a.filt_len;
@@ -1677,98 +1683,101 @@ __device__ __forceinline__ void ola_role(const OlaArgs &a, const int tile_i, con
     // (pv_engine.cc build_tiles) and every (stream, channel) row reuses it.  Frames that do not cover n
     // contribute an exact +0.0f (adding +0 never changes a sum that started at +0), so the loads are
     // unconditional on a clamped address: no divergent branch, and the compiler can batch them.
-    const float *__restrict__ fr = a.frames + (int64_t)row * a.FR * N;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const bool quads = nt == 256 && tile.n_cnt <= 4 * 126 && (N & 3) == 0;
-    if (!quads) copy_table(tid, nt);
+    const bool quads = NR == 2 && nt == 256 && tile.n_cnt <= 4 * 126 && (N & 3) == 0;
+    copy_table(tid, nt);
     __syncthreads();
     if (quads) {
-        // The gather is the kernel's largest part and it is bound by the number of load instructions, so two
-        // waves fetch the frames 16 bytes per lane while the other two copy the coefficient table.  A lane owns
-        // four consecutive tile samples; a frame starts anywhere, so its samples for those four sit in two
-        // neighbouring aligned 16-byte pieces: the lane loads the lower one and takes the upper one from the
+        // The gather is bound by the number of load instructions and by their latency: a lane owns four consecutive
+        // tile samples and fetches 16 bytes per frame.  A frame starts anywhere, so its samples for those four sit
+        // in two neighbouring aligned 16-byte pieces: the lane loads the lower one and takes the upper one from the
         // next lane (DPP wave shift; lane 63 of a wave only serves as its lane 62's neighbour, so a wave covers
-        // 63 quads and the two waves 126).
-        if (wave < 2) {
-            const int u = 63 * wave + lane;
-            const float4 *__restrict__ fr4 = reinterpret_cast<const float4 *>(fr);
-            const int nq = N >> 2;
-            const float4 w4 = reinterpret_cast<const float4 *>(wacc)[4 * u < a.lds_floats ? u : 0];
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            constexpr int kF = 4; // frames whose loads are in flight together
-            for (int j0 = 0; j0 < tile.t_cnt; j0 += kF) {
-                float4 Av[kF];
-                int spv[kF];
+        // 63 quads and a pair of waves 126).  Waves 0-1 gather the first row, waves 2-3 the second.
+        const int r = wave >> 1;
+        const bool row_ok = row0 + r < a.rows;
+        const float *__restrict__ fr = a.frames + (int64_t)(row_ok ? row0 + r : row0) * a.FR * N;
+        const int u = 63 * (wave & 1) + lane;
+        const float4 *__restrict__ fr4 = reinterpret_cast<const float4 *>(fr);
+        const int nq = N >> 2;
+        const float4 w4 = reinterpret_cast<const float4 *>(wacc)[4 * u < a.lds_floats ? u : 0];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        constexpr int kF = 4; // frames whose loads are in flight together
+        for (int j0 = 0; j0 < tile.t_cnt; j0 += kF) {
+            float4 Av[kF];
+            int spv[kF];
 #pragma unroll
-                for (int q = 0; q < kF; ++q) {
-                    const int j = j0 + q < tile.t_cnt ? j0 + q : tile.t_cnt - 1;
-                    spv[q] = sP[j];
-                    const int f0 = 4 * u - spv[q]; // frame sample under the quad's first tile sample
-                    const int r = (-spv[q]) & 3;   // where in its aligned piece that sample sits (wave-uniform)
-                    const int qf = (f0 - r) >> 2;
-                    const int qc = qf < 0 ? 0 : (qf >= nq ? nq - 1 : qf);
-                    const int slot = (tile.t_first + j) & (a.FR - 1);
-                    Av[q] = fr4[(int64_t)slot * nq + qc];
-                }
+            for (int q = 0; q < kF; ++q) {
+                const int j = j0 + q < tile.t_cnt ? j0 + q : tile.t_cnt - 1;
+                spv[q] = sP[j];
+                const int f0 = 4 * u - spv[q]; // frame sample under the quad's first tile sample
+                const int rr = (-spv[q]) & 3;  // where in its aligned piece that sample sits (wave-uniform)
+                const int qf = (f0 - rr) >> 2;
+                const int qc = qf < 0 ? 0 : (qf >= nq ? nq - 1 : qf);
+                const int slot = (tile.t_first + j) & (a.FR - 1);
+                Av[q] = fr4[(int64_t)slot * nq + qc];
+            }
 #pragma unroll
-                for (int q = 0; q < kF; ++q) {
-                    if (j0 + q >= tile.t_cnt) break; // wave-uniform
-                    const float4 A = Av[q];
-                    const int f0 = 4 * u - spv[q];
-                    const int r = (-spv[q]) & 3;
-                    float4 B;
-                    B.x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(A.x), 0x130, 0xf, 0xf, false));
-                    B.y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(A.y), 0x130, 0xf, 0xf, false));
-                    B.z = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(A.z), 0x130, 0xf, 0xf, false));
-                    float v0, v1, v2, v3;
-                    if (r == 0) {
-                        v0 = A.x, v1 = A.y, v2 = A.z, v3 = A.w;
-                    } else if (r == 1) {
-                        v0 = A.y, v1 = A.z, v2 = A.w, v3 = B.x;
-                    } else if (r == 2) {
-                        v0 = A.z, v1 = A.w, v2 = B.x, v3 = B.y;
-                    } else {
-                        v0 = A.w, v1 = B.x, v2 = B.y, v3 = B.z;
-                    }
-                    a0 += (f0 >= 0 && f0 < N) ? v0 : 0.f;
-                    a1 += (f0 + 1 >= 0 && f0 + 1 < N) ? v1 : 0.f;
-                    a2 += (f0 + 2 >= 0 && f0 + 2 < N) ? v2 : 0.f;
-                    a3 += (f0 + 3 >= 0 && f0 + 3 < N) ? v3 : 0.f;
+            for (int q = 0; q < kF; ++q) {
+                if (j0 + q >= tile.t_cnt) break; // wave-uniform
+                const float4 A = Av[q];
+                const int f0 = 4 * u - spv[q];
+                const int rr = (-spv[q]) & 3;
+                float4 B;
+                B.x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(A.x), 0x130, 0xf, 0xf, false));
+                B.y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(A.y), 0x130, 0xf, 0xf, false));
+                B.z = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(A.z), 0x130, 0xf, 0xf, false));
+                float v0, v1, v2, v3;
+                if (rr == 0) {
+                    v0 = A.x, v1 = A.y, v2 = A.z, v3 = A.w;
+                } else if (rr == 1) {
+                    v0 = A.y, v1 = A.z, v2 = A.w, v3 = B.x;
+                } else if (rr == 2) {
+                    v0 = A.z, v1 = A.w, v2 = B.x, v3 = B.y;
+                } else {
+                    v0 = A.w, v1 = B.x, v2 = B.y, v3 = B.z;
                 }
+                a0 += (f0 >= 0 && f0 < N) ? v0 : 0.f;
+                a1 += (f0 + 1 >= 0 && f0 + 1 < N) ? v1 : 0.f;
+                a2 += (f0 + 2 >= 0 && f0 + 2 < N) ? v2 : 0.f;
+                a3 += (f0 + 3 >= 0 && f0 + 3 < N) ? v3 : 0.f;
             }
-            if (lane < 63 && 4 * u < a.lds_floats) {
-                const int64_t n0 = tile.n_lo + 4 * u;
-                float4 y;
-                y.x = n0 >= 0 ? a0 / w4.x : 0.f;
-                y.y = n0 + 1 >= 0 ? a1 / w4.y : 0.f;
-                y.z = n0 + 2 >= 0 ? a2 / w4.z : 0.f;
-                y.w = n0 + 3 >= 0 ? a3 / w4.w : 0.f;
-                reinterpret_cast<float4 *>(ola)[u] = y;
-            }
-        } else {
-            copy_table(tid - 128, 128);
+        }
+        if (lane < 63 && 4 * u < a.lds_floats) {
+            const int64_t n0 = tile.n_lo + 4 * u;
+            float4 y;
+            y.x = n0 >= 0 ? a0 / w4.x : 0.f;
+            y.y = n0 + 1 >= 0 ? a1 / w4.y : 0.f;
+            y.z = n0 + 2 >= 0 ? a2 / w4.z : 0.f;
+            y.w = n0 + 3 >= 0 ? a3 / w4.w : 0.f;
+            reinterpret_cast<float4 *>(ola + r * a.lds_floats)[u] = y;
         }
     } else {
-        for (int i = tid; i < tile.n_cnt; i += nt) {
-            float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (row0 + r >= a.rows) break; // workgroup-uniform
+            const float *__restrict__ fr = a.frames + (int64_t)(row0 + r) * a.FR * N;
+            for (int i = tid; i < tile.n_cnt; i += nt) {
+                float acc = 0.f;
 #pragma unroll 4
-            for (int j = 0; j < tile.t_cnt; ++j) {
-                const int off = i - sP[j]; // n - P_t
-                const bool in = off >= 0 && off < N;
-                const int slot = (tile.t_first + j) & (a.FR - 1);
-                const float fv = fr[(int64_t)slot * N + (in ? off : 0)];
-                acc += in ? fv : 0.f;
+                for (int j = 0; j < tile.t_cnt; ++j) {
+                    const int off = i - sP[j]; // n - P_t
+                    const bool in = off >= 0 && off < N;
+                    const int slot = (tile.t_first + j) & (a.FR - 1);
+                    const float fv = fr[(int64_t)slot * N + (in ? off : 0)];
+                    acc += in ? fv : 0.f;
+                }
+                ola[r * a.lds_floats + i] = tile.n_lo + i >= 0 ? acc / wacc[i] : 0.f;
             }
-            ola[i] = tile.n_lo + i >= 0 ? acc / wacc[i] : 0.f;
         }
     }
     __syncthreads();
 
     if (tid >= tile.kcnt) return;
     const int64_t k = tile.k0 + tid;
-    float *__restrict__ out = a.out + (int64_t)row * a.out_stride_row + (k - a.k_base);
+    const int nr = a.rows - row0 < NR ? a.rows - row0 : NR; // rows this workgroup really has (>= 1)
+    float *__restrict__ out = a.out + (int64_t)row0 * a.out_stride_row + (k - a.k_base);
     if (!a.resample) {
-        *out = ola[tid];
+        for (int r = 0; r < nr; ++r) out[(int64_t)r * a.out_stride_row] = ola[r * a.lds_floats + tid];
         return;
     }
     const float *x = ola + (int)(oe.x & 0xffffu); // tap j = 0
@@ -1776,44 +1785,56 @@ __device__ __forceinline__ void ola_role(const OlaArgs &a, const int tile_i, con
         const int offset = (int)(oe.x >> 16);
         const float frac = __uint_as_float(oe.y);
         const float4 *__restrict__ T = tab4 + offset * (NF + 1);
-        v2f a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-#pragma unroll 8
+        v2f a01[NR], a23[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) a01[r] = v2f{0.f, 0.f}, a23[r] = v2f{0.f, 0.f};
+#pragma unroll 4
         for (int j = 0; j < NF; ++j) { // NF is a multiple of 4 (resample.c:687)
-            const float xv = x[j];
             const float4 c = T[j];
-            const v2f xx = {xv, xv};
             const v2f c01 = {c.x, c.y}, c23 = {c.z, c.w};
-            a01 += xx * c01; // -ffp-contract=off: separate multiply and add, per element, like the reference
-            a23 += xx * c23;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const float xv = x[r * a.lds_floats + j]; // a missing second row reads stale LDS: never stored
+                const v2f xx = {xv, xv};
+                a01[r] += xx * c01; // -ffp-contract=off: separate multiply and add, per element, like the reference
+                a23[r] += xx * c23;
+            }
         }
         // cubic_coef (resample.c:339-351)
         const float c0 = -0.16667f * frac + 0.16667f * frac * frac * frac;
         const float c1 = frac + 0.5f * frac * frac - 0.5f * frac * frac * frac;
         const float c3 = -0.33333f * frac + 0.5f * frac * frac - 0.16667f * frac * frac * frac;
         const float c2 = (float)(1. - c0 - c1 - c3);
-        *out = (c0 * a01.x) + (c1 * a01.y) + (c2 * a23.x) + (c3 * a23.y);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (r < nr)
+                out[(int64_t)r * a.out_stride_row] = (c0 * a01[r].x) + (c1 * a01[r].y) + (c2 * a23[r].x) + (c3 * a23[r].y);
     } else {
-        float sum = 0.f;
         const float *t = stab + (oe.x >> 16) * (uint32_t)NF;
-        for (int j = 0; j < NF; ++j) sum += x[j] * t[j];
-        *out = sum;
+        for (int r = 0; r < nr; ++r) {
+            float sum = 0.f;
+            for (int j = 0; j < NF; ++j) sum += x[r * a.lds_floats + j] * t[j];
+            out[(int64_t)r * a.out_stride_row] = sum;
+        }
     }
 }
 
+constexpr int kOlaRows = 2; // rows per workgroup of the batch / streaming overlap-add kernel
+
 __global__ __launch_bounds__(kTileOut) void pv_ola_kernel(const OlaArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    ola_role(a, blockIdx.x, blockIdx.y, smem_raw);
+    ola_role<kOlaRows>(a, blockIdx.x, blockIdx.y * kOlaRows, smem_raw);
 }
 
-size_t ola_lds_bytes(const OlaArgs &a) {
-    return (size_t)a.tab_bytes + sizeof(float) * (size_t)a.lds_floats + sizeof(int) * kMaxTileFrames;
+size_t ola_lds_bytes(const OlaArgs &a, int rows_per_group) {
+    return (size_t)a.tab_bytes + sizeof(float) * (size_t)a.lds_floats * rows_per_group + sizeof(int) * kMaxTileFrames;
 }
 
 void launch_ola(const OlaArgs &a, hipStream_t st) {
-    const size_t lds = ola_lds_bytes(a);
+    const size_t lds = ola_lds_bytes(a, kOlaRows);
     static bool big = false;
     allow_big_lds(pv_ola_kernel, big);
-    hipLaunchKernelGGL(pv_ola_kernel, dim3(a.ntiles, a.rows), dim3(kTileOut), lds, st, a);
+    hipLaunchKernelGGL(pv_ola_kernel, dim3(a.ntiles, (a.rows + kOlaRows - 1) / kOlaRows), dim3(kTileOut), lds, st, a);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1863,7 +1884,7 @@ template <int NC> __global__ __launch_bounds__(kStreamThreads) void pv_stream_ke
     stage_handoff();
     for (int tile = 0; tile < s.oa.ntiles; ++tile)
         for (int row = 0; row < rows; ++row) {
-            ola_role(s.oa, tile, row, smem_raw);
+            ola_role<1>(s.oa, tile, row, smem_raw);
             __syncthreads();
         }
 }
@@ -1874,7 +1895,7 @@ static size_t stream_lds_bytes(const StreamArgs &s) {
     const size_t m = (kStreamThreads / 64) * match_wave_lds(s.ma.hs, s.ma.PKP);
     if (s.coremode == 1 && m > lds) lds = m;
     if (s.coremode == 1 && seq_lds_bytes(s.qa) > lds) lds = seq_lds_bytes(s.qa);
-    if (ola_lds_bytes(s.oa) > lds) lds = ola_lds_bytes(s.oa);
+    if (ola_lds_bytes(s.oa, 1) > lds) lds = ola_lds_bytes(s.oa, 1);
     return lds;
 }
 
