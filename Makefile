@@ -5,8 +5,11 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  := gfx950
 # -ffp-contract=off is part of the numerical contract (see pv_kernels.hip header): no FMA contraction,
-# on the device or in the host planner.
-CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -Iaudiomod_amd/csrc -Wall -Wno-unused-result
+# on the device or in the host planner.  -fno-slp-vectorize: left alone, the compiler pairs neighbouring scalar
+# f32 adds / multiplies into v_pk_add_f32 / v_pk_mul_f32, which on gfx950 issue slower than the two scalar
+# instructions they replace (measured: analysis kernel -11 %, synthesis -3 %, overlap-add -5 % with the flag);
+# the one loop that gains from packed math (the resampler's) asks for it explicitly.  Same arithmetic either way.
+CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Iinclude -Iaudiomod_amd/csrc -Wall -Wno-unused-result
 SRC := audiomod_amd/csrc/pv_kernels.hip audiomod_amd/csrc/pv_engine.cc audiomod_amd/csrc/pv_plan.cc audiomod_amd/csrc/phasevocoder.cc
 HDR := $(wildcard audiomod_amd/csrc/*.h) $(wildcard include/*.h) $(wildcard include/dafx/*.h)
 LIB := audiomod_amd/lib/libaudiomod_pv.so

@@ -1697,6 +1697,11 @@ __device__ __forceinline__ void ola_role(const OlaArgs &a, const int tile_i, con
         const bool row_ok = row0 + r < a.rows;
         const float *__restrict__ fr = a.frames + (int64_t)(row_ok ? row0 + r : row0) * a.FR * N;
         const int u = 63 * (wave & 1) + lane;
+        // quads past the tile's last sample are never used (one more serves as the last one's DPP neighbour): they
+        // fetch what that neighbour fetches instead of frame data beyond the tile -- the 126 quads of a wave pair
+        // cover 504 samples, a tile needs ~400, and the difference was a fifth of the kernel's HBM reads
+        const int qmax = (tile.n_cnt + 3) >> 2;
+        const int ua = u < qmax ? u : qmax;
         const float4 *__restrict__ fr4 = reinterpret_cast<const float4 *>(fr);
         const int nq = N >> 2;
         const float4 w4 = reinterpret_cast<const float4 *>(wacc)[4 * u < a.lds_floats ? u : 0];
@@ -1709,8 +1714,8 @@ __device__ __forceinline__ void ola_role(const OlaArgs &a, const int tile_i, con
             for (int q = 0; q < kF; ++q) {
                 const int j = j0 + q < tile.t_cnt ? j0 + q : tile.t_cnt - 1;
                 spv[q] = sP[j];
-                const int f0 = 4 * u - spv[q]; // frame sample under the quad's first tile sample
-                const int rr = (-spv[q]) & 3;  // where in its aligned piece that sample sits (wave-uniform)
+                const int f0 = 4 * ua - spv[q]; // frame sample under the quad's first tile sample
+                const int rr = (-spv[q]) & 3;   // where in its aligned piece that sample sits (wave-uniform)
                 const int qf = (f0 - rr) >> 2;
                 const int qc = qf < 0 ? 0 : (qf >= nq ? nq - 1 : qf);
                 const int slot = (tile.t_first + j) & (a.FR - 1);
