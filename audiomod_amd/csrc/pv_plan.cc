@@ -376,7 +376,7 @@ int Planner::try_slice(std::vector<SliceRec> &out) {
     if (ws < required) {
         // The reference drops the slice here (processSliceForChannel :337-364: frame already added into the
         // accumulators, writeSlice skipped, so the following frames pile up on the same overlap-add position; the
-        // CONSTANT / vocoder loops even leave the channels in different states).  A run of dropped slices is
+        // CONSTANT loop even returns mid-way, leaving the channels in different states).  A run of dropped slices is
         // unbounded, the frame ring is not: refused, loudly, instead of reproduced.
         g_plan_reason = "more output pending than the reference's output ring holds: retrieve between calls";
         return PV_ERR_OUTPUT_OVERRUN;

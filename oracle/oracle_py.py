@@ -192,7 +192,7 @@ def have_ref():
 
 
 def ref_run(x, api="offline", block=480, flush=True, mode="normal_pitchshift", semitones=0.0, time_ratio=1.0,
-            coremode=1, fftsize=2048, sample_rate=48000):
+            coremode=1, fftsize=2048, sample_rate=48000, hopsize=0, timeout=None):
     x = np.ascontiguousarray(x, dtype=np.float32)
     ch, frames = x.shape
     m = MODES[mode] if isinstance(mode, str) else int(mode)
@@ -200,8 +200,9 @@ def ref_run(x, api="offline", block=480, flush=True, mode="normal_pitchshift", s
         fin, fout, fcnt = (os.path.join(d, n) for n in ("in.f32", "out.f32", "cnt.txt"))
         x.tofile(fin)
         cmd = [REF_DRIVER, api, fin, fout, fcnt, str(ch), str(frames), str(sample_rate), repr(float(time_ratio)),
-               repr(float(semitones)), str(m), str(coremode), str(fftsize), str(block), "1" if flush else "0"]
-        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+               repr(float(semitones)), str(m), str(coremode), str(fftsize), str(block), "1" if flush else "0",
+               str(hopsize)]
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
         with open(fcnt) as f:
             vals = [int(v) for v in f.read().split()]
         n = vals[0]

@@ -1186,15 +1186,17 @@ static int process_one_slice_vocoder(pvo *h) {
         /* writeSliceCarrier */
         const int s = (int)h->hop;
         if (ring_writespace(&ca->outbuf) < s) {
+            /* writeSliceCarrier returns 0 (:1205-1212) and processOneSliceVocoder ignores it (:186-191): the
+             * frame stays in the accumulators, the loop goes on to the next channel */
             fprintf(stderr, "pv_oracle: Buffer overrun on output for channel\n");
-            return 0;
+        } else {
+            for (int i = 0; i < s; ++i) ca->oacc[i] /= ca->wacc[i];
+            ring_write(&ca->outbuf, ca->oacc, s);
+            memmove(ca->oacc, ca->oacc + s, sizeof(float) * (N - s));
+            memset(ca->oacc + N - s, 0, sizeof(float) * s);
+            memmove(ca->wacc, ca->wacc + s, sizeof(float) * (N - s));
+            memset(ca->wacc + N - s, 0, sizeof(float) * s);
         }
-        for (int i = 0; i < s; ++i) ca->oacc[i] /= ca->wacc[i];
-        ring_write(&ca->outbuf, ca->oacc, s);
-        memmove(ca->oacc, ca->oacc + s, sizeof(float) * (N - s));
-        memset(ca->oacc + N - s, 0, sizeof(float) * s);
-        memmove(ca->wacc, ca->wacc + s, sizeof(float) * (N - s));
-        memset(ca->wacc + N - s, 0, sizeof(float) * s);
         ad->slicecnt++;
         ca->slicecnt++;
     }

@@ -26,7 +26,7 @@
 
 int main(int argc, char **argv) {
     if (argc < 15) {
-        fprintf(stderr, "usage: %s api in out counts ch frames sr timeratio semis mode coremode fft block flush\n", argv[0]);
+        fprintf(stderr, "usage: %s api in out counts ch frames sr timeratio semis mode coremode fft block flush [hopsize]\n", argv[0]);
         return 2;
     }
     std::string api = argv[1];
@@ -41,6 +41,7 @@ int main(int argc, char **argv) {
     int fftsize = atoi(argv[12]);
     int block = atoi(argv[13]);
     int flush = atoi(argv[14]);
+    int hopsize = argc > 15 ? atoi(argv[15]) : 0; // 0 = automatic (phasevocoder.h:54)
 
     std::vector<std::vector<float>> in(ch, std::vector<float>(frames));
     FILE *f = fopen(inpath, "rb");
@@ -50,7 +51,7 @@ int main(int argc, char **argv) {
     }
     fclose(f);
 
-    audiomod::phasevocoder pv(sr, ch, timeratio, semis, mode, coremode, fftsize);
+    audiomod::phasevocoder pv(sr, ch, timeratio, semis, mode, coremode, fftsize, hopsize);
     modbase *rt = &pv;
     modbase_offline *off = &pv;
 
@@ -59,6 +60,10 @@ int main(int argc, char **argv) {
     std::vector<float *> buff(ch), outbuff(ch);
     std::vector<std::vector<float>> bstore(ch, std::vector<float>(block)), ostore(ch, std::vector<float>(block * 64));
     for (int c = 0; c < ch; ++c) { buff[c] = bstore[c].data(); outbuff[c] = ostore[c].data(); }
+    auto grow = [&](int n) { // one call can yield more than 64 blocks' worth (small calls, large hops)
+        if ((size_t)n <= ostore[0].size()) return;
+        for (int c = 0; c < ch; ++c) { ostore[c].resize((size_t)n); outbuff[c] = ostore[c].data(); }
+    };
 
     if (api == "offline") {
         long produced = 0;
@@ -67,6 +72,7 @@ int main(int argc, char **argv) {
             for (int c = 0; c < ch; ++c) memcpy(buff[c], in[c].data() + i, n * sizeof(float));
             off->processInData(buff.data(), n);
             int got = off->getOutSamples();
+            grow(got);
             off->getOutData(outbuff.data(), got);
             for (int c = 0; c < ch; ++c) out[c].insert(out[c].end(), outbuff[c], outbuff[c] + got);
             counts.push_back(got);
@@ -77,6 +83,7 @@ int main(int argc, char **argv) {
             while (produced < frames) {
                 off->processInData(buff.data(), block);
                 int got = off->getOutSamples();
+                grow(got);
                 off->getOutData(outbuff.data(), got);
                 counts.push_back(got);
                 int w = got;
