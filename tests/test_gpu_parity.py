@@ -21,7 +21,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def rms(a, b):
-    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+    """RMS difference over the samples that are finite in the expected output `b`.  The reference emits NaN in a
+    few situations (its Rosenberg carrier below ~22 kHz); there the engine has to be non-finite at the same
+    positions: inf is returned if it is not."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    fin = np.isfinite(b)
+    if a.shape != b.shape or not np.array_equal(np.isfinite(a), fin):
+        return float("inf")
+    return float(np.sqrt(np.mean((a[fin] - b[fin]) ** 2))) if fin.any() else 0.0
 
 
 @pytest.mark.parametrize("name", e2e_cases())
@@ -35,7 +42,8 @@ def test_golden_streaming(name):
     assert cnt == counts
     assert got.shape == y.shape
     assert rms(got, y) <= RMS_TOL
-    assert np.max(np.abs(got - y)) <= 2e-3
+    fin = np.isfinite(y)
+    assert np.max(np.abs(got[fin] - y[fin]), initial=0.0) <= 2e-3
 
 
 @pytest.mark.parametrize("name", [n for n in e2e_cases() if not n.startswith("rt_")])

@@ -42,6 +42,12 @@ E2E = [
     ("whisper_2048", "voice2", dict(mode="whisper")),
     ("vocoder_rosenberg", "voice2", dict(mode="vocoder")),
     ("vocoder_chord", "voice2", dict(mode="vocoder_chord")),
+    # from the randomised sweeps (tools/fuzz_parity.py, tools/fuzz_oracle_vs_ref.py)
+    ("hop300_shift-5_1024_44k", "voice2", dict(semitones=-5.0, fftsize=1024, hopsize=300, sample_rate=44100)),
+    ("vocoder_16k_nan_carrier", "voice2", dict(mode="vocoder", sample_rate=16000)),
+    ("stretch0.374_256_cm0", "voice2", dict(mode="time_stretch", time_ratio=0.374, fftsize=256, coremode=0, flush=False)),
+    ("robotic-15.8_1024_16k_block4724", "voice2", dict(mode="robotic", fftsize=1024, sample_rate=16000, semitones=-15.8,
+                                                     block=4724)),
 ]
 
 
@@ -65,7 +71,10 @@ def main():
     subprocess.check_call(["make", "-s", "-f", "oracle/ref.mk"], cwd=ROOT)
     os.makedirs(GOLD, exist_ok=True)
 
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]  # names to (re)generate; none = everything
     for name, kind, kw in E2E:
+        if only and name not in only:
+            continue
         x = make_signal(kind)
         xi = np.round(x * 32768.0).astype(np.int16)
         assert np.array_equal(xi.astype(np.float32) / 32768.0, x)
@@ -74,6 +83,8 @@ def main():
         np.savez_compressed(os.path.join(GOLD, f"e2e_{name}.npz"), x_i16=xi, y=y, counts=np.array(counts, np.int32),
                             meta=np.array(repr(meta)))
         print(f"e2e_{name}: in {x.shape} out {y.shape} calls {len(counts)}")
+    if only:
+        return
 
     # ---- WAV goldens from the reference's own CLI: input WAV + the WAV audiomod-exe writes ----
     import wave
