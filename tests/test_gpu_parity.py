@@ -475,6 +475,18 @@ def test_process_block_ignores_time_stretch():
     assert bits_equal(got, x) and bits_equal(want, x)
 
 
+def test_randomised_sweep_slice():
+    """120 configurations of tools/fuzz_parity.py (seed 7): streaming API, batch API on every second case and the
+    processBlock loop on every third, against the oracle.  The full sweeps are in profiles/r01."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "120", "7", "300"],
+                       capture_output=True, text=True, timeout=900)
+    tail = "\n".join(line for line in r.stdout.splitlines() if not line.startswith("#"))[-2000:]
+    assert r.returncode == 0, tail
+    assert " 0 failed" in r.stdout, tail
+
+
 def test_batch_with_no_output_at_all():
     """Shorter than one FFT frame and no flush (the time_stretch rule, main.cc:471-478): zero output frames is a
     valid job, not an argument error."""
