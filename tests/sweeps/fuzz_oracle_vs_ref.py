@@ -2,7 +2,7 @@
 """Randomised pinning of the oracle against the COMPILED REFERENCE (oracle/_ref/ref_driver; only where
 /root/reference exists, i.e. in the build container): random configurations through both, outputs compared bit for
 bit (NaN where the reference has NaN), per-call counts equal.  CPU only.
-usage: tools/fuzz_oracle_vs_ref.py [cases] [seed]"""
+usage: tests/sweeps/fuzz_oracle_vs_ref.py [cases] [seed]"""
 import os
 import subprocess
 import sys
@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from audiomod_amd import signals  # noqa: E402
 from oracle import oracle_py as O  # noqa: E402

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU: random configurations (mode, pitch, ratio, core mode, FFT size, hop, rate,
 channels, length, call size, signal) through the streaming and the batch API against the oracle.  Prints one line
-per case and a summary; exit code 1 if any case fails.  usage: tools/fuzz_parity.py [cases] [seed] [seconds]"""
+per case and a summary; exit code 1 if any case fails.  usage: tests/sweeps/fuzz_parity.py [cases] [seed] [seconds]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from audiomod_amd import engine as E  # noqa: E402
 from audiomod_amd import signals  # noqa: E402

@@ -429,7 +429,7 @@ def test_formant_cepstral_needs_a_wave_fft_size():
         E.PhaseVocoder(48000, 2, 1.0, 4.0, E.FORMANT_CEPSTRAL, 1, 1024)
 
 
-# Configurations the randomised sweep (tools/fuzz_parity.py) turned up as refused or wrong at some point.
+# Configurations the randomised sweep (tests/sweeps/fuzz_parity.py) turned up as refused or wrong at some point.
 SWEEP_FINDS = [
     # per-call output above the streaming staging buffer: fixed-hop modes through a > 2x up-sampling resampler
     (dict(mode="robotic", fftsize=1024, sample_rate=16000, semitones=-15.8), 2, 887, 4724, True),
@@ -476,11 +476,11 @@ def test_process_block_ignores_time_stretch():
 
 
 def test_randomised_sweep_slice():
-    """120 configurations of tools/fuzz_parity.py (seed 7): streaming API, batch API on every second case and the
+    """120 configurations of tests/sweeps/fuzz_parity.py (seed 7): streaming API, batch API on every second case and the
     processBlock loop on every third, against the oracle.  The full sweeps are in profiles/r01."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "120", "7", "300"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sweeps", "fuzz_parity.py"), "120", "7", "300"],
                        capture_output=True, text=True, timeout=900)
     tail = "\n".join(line for line in r.stdout.splitlines() if not line.startswith("#"))[-2000:]
     assert r.returncode == 0, tail

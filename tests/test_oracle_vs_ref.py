@@ -49,14 +49,14 @@ def test_chunking_independence():
 
 
 def test_random_configurations_bit_identical_to_the_reference():
-    """A slice of tools/fuzz_oracle_vs_ref.py (the full sweep: profiles/r01/fuzz_oracle_vs_ref_summary.txt):
+    """A slice of tests/sweeps/fuzz_oracle_vs_ref.py (the full sweep: profiles/r01/fuzz_oracle_vs_ref_summary.txt):
     random mode / pitch / ratio / FFT size / hop / rate / channels / call size through the oracle and through the
     compiled reference, offline and real-time loops, outputs compared bit for bit."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_oracle_vs_ref.py"), "120", "9"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "sweeps", "fuzz_oracle_vs_ref.py"), "120", "9"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "differing or failed: 0" in r.stdout

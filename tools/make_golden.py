@@ -42,7 +42,7 @@ E2E = [
     ("whisper_2048", "voice2", dict(mode="whisper")),
     ("vocoder_rosenberg", "voice2", dict(mode="vocoder")),
     ("vocoder_chord", "voice2", dict(mode="vocoder_chord")),
-    # from the randomised sweeps (tools/fuzz_parity.py, tools/fuzz_oracle_vs_ref.py)
+    # from the randomised sweeps (tests/sweeps/fuzz_parity.py, tests/sweeps/fuzz_oracle_vs_ref.py)
     ("hop300_shift-5_1024_44k", "voice2", dict(semitones=-5.0, fftsize=1024, hopsize=300, sample_rate=44100)),
     ("vocoder_16k_nan_carrier", "voice2", dict(mode="vocoder", sample_rate=16000)),
     ("stretch0.374_256_cm0", "voice2", dict(mode="time_stretch", time_ratio=0.374, fftsize=256, coremode=0, flush=False)),
