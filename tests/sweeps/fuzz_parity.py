@@ -126,16 +126,22 @@ def main():
         okb = True
         if frames >= 1 and i % 2 == 0:
             import torch
-            x2 = signal(kind, frames, ch, 5000 + i)
+            # 2 ... 24 streams (its own generator: the case sequence stays what it was), every stream its own input
+            ns = int(np.random.default_rng(seed * 100003 + i).choice([2, 2, 3, 5, 9, 24])) if frames <= 20000 else 2
+            xs = [x] + [signal(kind, frames, ch, 5000 + 37 * i + k) for k in range(1, ns)]
             try:
-                b = E.Batch(2, frames, channels=ch, block=block, flush=flush, **kw)
-                out = b.run(torch.from_numpy(np.stack([x, x2])).cuda())
+                b = E.Batch(ns, frames, channels=ch, block=block, flush=flush, **kw)
+                out = b.run(torch.from_numpy(np.stack(xs)).cuda())
                 torch.cuda.synchronize()
                 out = out.cpu().numpy()
                 b.close()
-                want2, _, _ = O.run_offline(x2, block=block, flush=flush, **kw)
                 okb = out.shape[2] == want.shape[1]
-                rb = max(rms(out[0], want), rms(out[1], want2)) if okb else float("nan")
+                rb = float("nan")
+                if okb:
+                    rb = rms(out[0], want)
+                    for k in range(1, ns):
+                        wk, _, _ = O.run_offline(xs[k], block=block, flush=flush, **kw)
+                        rb = max(rb, rms(out[k], wk))
                 okb = okb and rb <= RMS_TOL
             except E.PvError as ex:
                 unsupported.append(tag + f" [batch] -> {ex}")
