@@ -1426,6 +1426,13 @@ void launch_synth(const SynthArgs &a, hipStream_t st) {
         } else {
             constexpr int WPB = 1;
             const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
+            const bool lock_only = !a.do_freq_comp && a.voc_band_len < 0 && !a.robotic && !a.passthru && !a.whisper &&
+                                   a.coremode == 1;
+            if (lock_only) {
+                hipLaunchKernelGGL((pv_synth_wave_kernel<2048, WPB, true>), dim3(grid), dim3(64 * WPB),
+                                   WPB * WF<2048>::LDS_CF * sizeof(cf), st, a);
+                return;
+            }
             static bool big2 = false;
             allow_big_lds(pv_synth_wave_kernel<2048, WPB>, big2);
             hipLaunchKernelGGL((pv_synth_wave_kernel<2048, WPB>), dim3(grid), dim3(64 * WPB),
