@@ -1407,13 +1407,22 @@ pv_synth_wave_kernel(const SynthArgs a) {
     synth_wave_role<NC, kLockOnly>(a, row, tl, lds);
 }
 
+// AUDIOMOD_PV_SYNTH_GENERIC=1: every mode through the all-modes kernel (tests compare it with the specialisation)
+static bool synth_generic_only() {
+    static const bool on = [] {
+        const char *e = getenv("AUDIOMOD_PV_SYNTH_GENERIC");
+        return e && atoi(e) != 0;
+    }();
+    return on;
+}
+
 void launch_synth(const SynthArgs &a, hipStream_t st) {
     if (a.tb.nc == 1024 || a.tb.nc == 2048) {
         if (a.tb.nc == 1024) {
             constexpr int WPB = 1;
             const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
             const bool lock_only = !a.do_freq_comp && a.voc_band_len < 0 && !a.robotic && !a.passthru && !a.whisper &&
-                                   a.coremode == 1;
+                                   a.coremode == 1 && !synth_generic_only();
             if (lock_only) {
                 hipLaunchKernelGGL((pv_synth_wave_kernel<1024, WPB, true>), dim3(grid), dim3(64 * WPB),
                                    WPB * WF<1024>::LDS_CF * sizeof(cf), st, a);
@@ -1427,7 +1436,7 @@ void launch_synth(const SynthArgs &a, hipStream_t st) {
             constexpr int WPB = 1;
             const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
             const bool lock_only = !a.do_freq_comp && a.voc_band_len < 0 && !a.robotic && !a.passthru && !a.whisper &&
-                                   a.coremode == 1;
+                                   a.coremode == 1 && !synth_generic_only();
             if (lock_only) {
                 hipLaunchKernelGGL((pv_synth_wave_kernel<2048, WPB, true>), dim3(grid), dim3(64 * WPB),
                                    WPB * WF<2048>::LDS_CF * sizeof(cf), st, a);

@@ -475,6 +475,41 @@ def test_process_block_ignores_time_stretch():
     assert bits_equal(got, x) and bits_equal(want, x)
 
 
+def test_synthesis_specialisation_is_bit_identical_to_the_generic_kernel():
+    """The plain phase-locked case runs a specialisation of the synthesis kernel (mode switches folded at compile
+    time); AUDIOMOD_PV_SYNTH_GENERIC=1 (read once per process, hence the child) sends it through the all-modes
+    kernel instead.  Same arithmetic: the outputs must agree bit for bit, at 2048 and 4096 points."""
+    import subprocess
+    import sys
+    code = """
+import numpy as np, sys, torch
+sys.path.insert(0, %r)
+from audiomod_amd import engine as E, signals
+x = np.stack([signals.voice(30000, 2, seed=11 + s) for s in range(3)])
+outs = []
+for kw in (dict(semitones=4.0), dict(mode="time_stretch", time_ratio=1.5, fftsize=4096, flush=False)):
+    b = E.Batch(3, 30000, channels=2, **kw)
+    o = b.run(torch.from_numpy(x).cuda()); torch.cuda.synchronize()
+    outs.append(o.cpu().numpy()); b.close()
+    g, _ = E.run_offline(x[0], **kw)
+    outs.append(g)
+np.savez(sys.argv[1], *outs)
+""" % (ROOT,)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        files = []
+        for tag, env in (("spec", {}), ("generic", {"AUDIOMOD_PV_SYNTH_GENERIC": "1"})):
+            f = os.path.join(d, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,
+                               env=dict(os.environ, **env), timeout=600)
+            assert r.returncode == 0, r.stdout + r.stderr
+            files.append(np.load(f))
+        a, b = files
+        assert len(a.files) == len(b.files) == 4
+        for k in a.files:
+            assert bits_equal(a[k], b[k]), k
+
+
 def test_randomised_sweep_slice():
     """120 configurations of tests/sweeps/fuzz_parity.py (seed 7): streaming API, batch API on every second case and the
     processBlock loop on every third, against the oracle.  The full sweeps are in profiles/r01."""
