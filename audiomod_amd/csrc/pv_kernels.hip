@@ -27,6 +27,7 @@
 #include "pv_wavefft.h"
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 namespace pv {
 
