@@ -1049,13 +1049,14 @@ __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a
 // synthesis, wave-per-frame variant.  The wave-private LDS region is reused four times:
 // [output phases + rot/peak lists] -> [spectrum X] -> [butterfly-ordered input] -> [time-domain frame].
 // --------------------------------------------------------------------------------------------
-template <int NC, bool kLockOnly = false>
+template <int NC, int kPlainCore = -1>
 __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int row, const int tl, cf *lds) {
-    // kLockOnly: the plain phase-locked pitch shift / stretch (no frequency compression, vocoder, robotic, whisper
-    // or pass-through source): the mode switches fold away, the kernel is half the code
+    // kPlainCore >= 0: the plain pitch shift / stretch in that core mode (no frequency compression, vocoder,
+    // robotic, whisper or pass-through source): the mode switches fold away, the kernel is half the code
     SynthArgs a = a_in;
-    if (kLockOnly) {
-        a.do_freq_comp = 0, a.voc_band_len = -1, a.robotic = 0, a.passthru = 0, a.whisper = nullptr, a.coremode = 1;
+    if (kPlainCore >= 0) {
+        a.do_freq_comp = 0, a.voc_band_len = -1, a.robotic = 0, a.passthru = 0, a.whisper = nullptr;
+        a.coremode = kPlainCore;
     }
     using W = WF<NC>;
     constexpr int N = 2 * NC, hs = NC, R = W::R;
@@ -1398,14 +1399,14 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
 }
 
 // (N = 2048 is asked to fit four waves per SIMD, 128 VGPRs; the compiler gets there without spilling)
-template <int NC, int WPB, bool kLockOnly = false>
+template <int NC, int WPB, int kPlainCore = -1>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(NC == 1024 ? 4 : 1))) void
 pv_synth_wave_kernel(const SynthArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cf *lds = reinterpret_cast<cf *>(smem_raw) + (threadIdx.x >> 6) * WF<NC>::LDS_CF;
     int row, tl;
     if (!block_to_row_slice_w<WPB>(a.Tn, a.rows, row, tl)) return; // wave-uniform
-    synth_wave_role<NC, kLockOnly>(a, row, tl, lds);
+    synth_wave_role<NC, kPlainCore>(a, row, tl, lds);
 }
 
 // AUDIOMOD_PV_SYNTH_GENERIC=1: every mode through the all-modes kernel (tests compare it with the specialisation)
@@ -1422,11 +1423,13 @@ void launch_synth(const SynthArgs &a, hipStream_t st) {
         if (a.tb.nc == 1024) {
             constexpr int WPB = 1;
             const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
-            const bool lock_only = !a.do_freq_comp && a.voc_band_len < 0 && !a.robotic && !a.passthru && !a.whisper &&
-                                   a.coremode == 1 && !synth_generic_only();
-            if (lock_only) {
-                hipLaunchKernelGGL((pv_synth_wave_kernel<1024, WPB, true>), dim3(grid), dim3(64 * WPB),
-                                   WPB * WF<1024>::LDS_CF * sizeof(cf), st, a);
+            const bool plain = !a.do_freq_comp && a.voc_band_len < 0 && !a.robotic && !a.passthru && !a.whisper &&
+                               !synth_generic_only();
+            if (plain && a.coremode >= 0 && a.coremode <= 2) {
+                const size_t lds = WPB * WF<1024>::LDS_CF * sizeof(cf);
+                if (a.coremode == 1) hipLaunchKernelGGL((pv_synth_wave_kernel<1024, WPB, 1>), dim3(grid), dim3(64 * WPB), lds, st, a);
+                else if (a.coremode == 0) hipLaunchKernelGGL((pv_synth_wave_kernel<1024, WPB, 0>), dim3(grid), dim3(64 * WPB), lds, st, a);
+                else hipLaunchKernelGGL((pv_synth_wave_kernel<1024, WPB, 2>), dim3(grid), dim3(64 * WPB), lds, st, a);
                 return;
             }
             static bool big1 = false;
@@ -1436,11 +1439,13 @@ void launch_synth(const SynthArgs &a, hipStream_t st) {
         } else {
             constexpr int WPB = 1;
             const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
-            const bool lock_only = !a.do_freq_comp && a.voc_band_len < 0 && !a.robotic && !a.passthru && !a.whisper &&
-                                   a.coremode == 1 && !synth_generic_only();
-            if (lock_only) {
-                hipLaunchKernelGGL((pv_synth_wave_kernel<2048, WPB, true>), dim3(grid), dim3(64 * WPB),
-                                   WPB * WF<2048>::LDS_CF * sizeof(cf), st, a);
+            const bool plain = !a.do_freq_comp && a.voc_band_len < 0 && !a.robotic && !a.passthru && !a.whisper &&
+                               !synth_generic_only();
+            if (plain && a.coremode >= 0 && a.coremode <= 2) {
+                const size_t lds = WPB * WF<2048>::LDS_CF * sizeof(cf);
+                if (a.coremode == 1) hipLaunchKernelGGL((pv_synth_wave_kernel<2048, WPB, 1>), dim3(grid), dim3(64 * WPB), lds, st, a);
+                else if (a.coremode == 0) hipLaunchKernelGGL((pv_synth_wave_kernel<2048, WPB, 0>), dim3(grid), dim3(64 * WPB), lds, st, a);
+                else hipLaunchKernelGGL((pv_synth_wave_kernel<2048, WPB, 2>), dim3(grid), dim3(64 * WPB), lds, st, a);
                 return;
             }
             static bool big2 = false;

@@ -476,8 +476,8 @@ def test_process_block_ignores_time_stretch():
 
 
 def test_synthesis_specialisation_is_bit_identical_to_the_generic_kernel():
-    """The plain phase-locked case runs a specialisation of the synthesis kernel (mode switches folded at compile
-    time); AUDIOMOD_PV_SYNTH_GENERIC=1 (read once per process, hence the child) sends it through the all-modes
+    """The plain pitch-shift / stretch cases (any core mode) run specialisations of the synthesis kernel (mode
+    switches folded at compile time); AUDIOMOD_PV_SYNTH_GENERIC=1 (read once per process, hence the child) sends it through the all-modes
     kernel instead.  Same arithmetic: the outputs must agree bit for bit, at 2048 and 4096 points."""
     import subprocess
     import sys
@@ -487,7 +487,8 @@ sys.path.insert(0, %r)
 from audiomod_amd import engine as E, signals
 x = np.stack([signals.voice(30000, 2, seed=11 + s) for s in range(3)])
 outs = []
-for kw in (dict(semitones=4.0), dict(mode="time_stretch", time_ratio=1.5, fftsize=4096, flush=False)):
+for kw in (dict(semitones=4.0), dict(mode="time_stretch", time_ratio=1.5, fftsize=4096, flush=False),
+           dict(semitones=-3.0, coremode=0), dict(semitones=12.0, coremode=2), dict(semitones=5.0, coremode=0, fftsize=4096)):
     b = E.Batch(3, 30000, channels=2, **kw)
     o = b.run(torch.from_numpy(x).cuda()); torch.cuda.synchronize()
     outs.append(o.cpu().numpy()); b.close()
@@ -505,7 +506,7 @@ np.savez(sys.argv[1], *outs)
             assert r.returncode == 0, r.stdout + r.stderr
             files.append(np.load(f))
         a, b = files
-        assert len(a.files) == len(b.files) == 4
+        assert len(a.files) == len(b.files) == 10
         for k in a.files:
             assert bits_equal(a[k], b[k]), k
 
