@@ -1683,8 +1683,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // with NR = 2 a workgroup fetches them once for two rows, each resampler thread reads a coefficient once for two
 // outputs (the loop is bound by LDS reads), and the dependent chain descriptor -> offsets -> frame gather ->
 // resample, which at full occupancy is what the kernel waits on, is paid once for twice the work.
-template <int NR>
-__device__ __forceinline__ void ola_role(const OlaArgs &a, const int tile_i, const int row0, char *smem_raw) {
+// kRes: -1 = resampling mode read from the arguments; 0 = none, 1 = direct sinc table, 2 = cubic-interpolated table
+// (the argument's flags become compile-time constants)
+template <int NR, int kRes = -1>
+__device__ __forceinline__ void ola_role(const OlaArgs &a_in, const int tile_i, const int row0, char *smem_raw) {
+    OlaArgs a = a_in;
+    if (kRes >= 0) a.resample = kRes != 0, a.interp = kRes == 2;
     // interpolated mode: coefficient table expanded per sub-sample offset, tab4[off][j] = the four taps
     // sinc[4 + (j+1)*ov - off + {-2,-1,0,1}] of resampler_basic_interpolate_single (resample.c:494-535) as one
     // aligned float4; rows are padded to NF+1 slots so the (at most ov) distinct rows a wave reads in one
@@ -1861,9 +1865,9 @@ __device__ __forceinline__ void ola_role(const OlaArgs &a, const int tile_i, con
 
 constexpr int kOlaRows = 2; // rows per workgroup of the batch / streaming overlap-add kernel
 
-__global__ __launch_bounds__(kTileOut) void pv_ola_kernel(const OlaArgs a) {
+template <int kRes> __global__ __launch_bounds__(kTileOut) void pv_ola_kernel(const OlaArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    ola_role<kOlaRows>(a, blockIdx.x, blockIdx.y * kOlaRows, smem_raw);
+    ola_role<kOlaRows, kRes>(a, blockIdx.x, blockIdx.y * kOlaRows, smem_raw);
 }
 
 size_t ola_lds_bytes(const OlaArgs &a, int rows_per_group) {
@@ -1872,9 +1876,18 @@ size_t ola_lds_bytes(const OlaArgs &a, int rows_per_group) {
 
 void launch_ola(const OlaArgs &a, hipStream_t st) {
     const size_t lds = ola_lds_bytes(a, kOlaRows);
-    static bool big = false;
-    allow_big_lds(pv_ola_kernel, big);
-    hipLaunchKernelGGL(pv_ola_kernel, dim3(a.ntiles, (a.rows + kOlaRows - 1) / kOlaRows), dim3(kTileOut), lds, st, a);
+    const dim3 grid(a.ntiles, (a.rows + kOlaRows - 1) / kOlaRows);
+    static bool big0 = false, big1 = false, big2 = false;
+    if (!a.resample) {
+        allow_big_lds(pv_ola_kernel<0>, big0);
+        hipLaunchKernelGGL(pv_ola_kernel<0>, grid, dim3(kTileOut), lds, st, a);
+    } else if (!a.interp) {
+        allow_big_lds(pv_ola_kernel<1>, big1);
+        hipLaunchKernelGGL(pv_ola_kernel<1>, grid, dim3(kTileOut), lds, st, a);
+    } else {
+        allow_big_lds(pv_ola_kernel<2>, big2);
+        hipLaunchKernelGGL(pv_ola_kernel<2>, grid, dim3(kTileOut), lds, st, a);
+    }
 }
 
 // --------------------------------------------------------------------------------------------

@@ -21,6 +21,8 @@ def canonical(k):
         return "pv_analyze_kernel"
     if k.startswith("pv_synth_wave_kernel"):
         return "pv_synth_kernel"
+    if k.startswith("pv_ola_kernel"):  # pv_ola_kernel<resampling mode>
+        return "pv_ola_kernel"
     return k
 
 
