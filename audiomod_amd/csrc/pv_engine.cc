@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <string>
 #include <vector>
@@ -99,6 +100,110 @@ template <typename T> struct PinBuf {
 // ------------------------------------------------------------------------------------------
 // Core: device-resident tables, intermediates and per-stream state for S streams x C channels.
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Host plan of the fused synthesis + overlap-add kernel: for every slice, where its frame lands in the rings,
+// the window-sum denominators of the samples it finalises and the resampler's positions for the outputs its wave
+// emits.  All of it is data-independent and the same for every row, so it is computed once per slice here
+// (64-bit divisions, float window sums in the reference's order) and the kernel only looks things up.
+// ------------------------------------------------------------------------------------------
+struct ChainBuilder {
+    const Derived &d;
+    int AR, SR;
+    int64_t E = 0;       // outputs handed to waves so far
+    bool started = false;
+    struct Live {
+        int64_t P;
+        int32_t flags;
+    };
+    std::deque<Live> live; // frames that may still cover samples not yet finalised, oldest first
+    bool any_upper_skip = false;
+
+    ChainBuilder(const Derived &dd, int ar, int sr) : d(dd), AR(ar), SR(sr) {}
+
+    static int32_t pmod(int64_t v, int m) {
+        int64_t r = v % m;
+        return (int32_t)(r < 0 ? r + m : r);
+    }
+    // window-sum denominator of OLA sample n at the moment writeSlice divides (channelinfo.cc:108 seeds [0] with
+    // 1; synthesiseSlice :1073 adds w[i] * float(area * 1.5) per frame, oldest frame first)
+    float denominator(int64_t n, bool upper) const {
+        float acc = n == 0 ? 1.f : 0.f;
+        for (const Live &f : live) {
+            if (upper && (f.flags & kSliceUpperChannelsSkip)) continue;
+            const int64_t off = n - f.P;
+            if (off >= 0 && off < d.N) acc += d.window[(size_t)off] * d.win_gain;
+        }
+        return acc;
+    }
+    // One slice.  last_of_launch: its wave also emits the outputs that do not fill a block of 64.
+    // out_limit: outputs at or beyond it are not written (the CLI truncates to the input length).
+    void add(const SliceRec &r, bool last_of_launch, int64_t out_limit, std::vector<ChainSlice> &cs,
+             std::vector<float> &wden, std::vector<float> &wden_hi, std::vector<uint2> &otab) {
+        ChainSlice c{};
+        c.acc_pos = pmod(r.P, AR);
+        c.str_pos = pmod(r.P, SR);
+        c.adv = r.adv;
+        c.flags = r.flags;
+        if (r.flags & kSliceUpperChannelsSkip) any_upper_skip = true;
+        live.push_back(Live{r.P, r.flags});
+        c.wden_off = (int32_t)wden.size();
+        for (int i = 0; i < r.adv; ++i) {
+            wden.push_back(denominator(r.P + i, false));
+            wden_hi.push_back(any_upper_skip ? denominator(r.P + i, true) : wden.back());
+        }
+        const int64_t Pn = r.P + r.adv;
+        while (!live.empty() && live.front().P + d.N <= Pn) live.pop_front();
+        // outputs: every k below K0 + cnt is computable now; whole blocks of 64 go to this wave, the remainder to
+        // the next slice's (a wave's lanes then always work in full rows), except at the end of a launch
+        const int64_t Kn = r.K0 + r.cnt;
+        int64_t Eto = d.resample ? (last_of_launch ? Kn : (Kn / 64) * 64) : Kn;
+        if (Eto < E) Eto = E;
+        int64_t lo = E, hi = Eto;
+        if (!d.resample) lo = r.K0, hi = Kn; // outputs are the finalised samples themselves
+        if (hi > out_limit) hi = out_limit;
+        if (lo > hi) lo = hi;
+        c.k_off = (int32_t)(lo - launch_k0);
+        c.kcnt = (int32_t)(hi - lo);
+        c.otab_off = (int32_t)otab.size();
+        if (d.resample) {
+            for (int64_t k = lo; k < hi; ++k) {
+                // last_sample = filt_len/2 + floor(k*num/den), samp_frac_num = (k*num) mod den: closed form of
+                // resample.c:548-554 from skip_zeros (:1225); sub-sample offset and interpolation fraction as
+                // resampler_basic_interpolate_single computes them (:494-500)
+                const unsigned __int128 tot = (unsigned __int128)k * d.res_num;
+                const int64_t pos = (int64_t)(d.filt_len / 2) + (int64_t)(tot / d.res_den);
+                const uint32_t frac_num = (uint32_t)(tot % d.res_den);
+                uint32_t sub, fbits = 0;
+                if (d.interp) {
+                    const uint32_t ov = (uint32_t)d.oversample;
+                    sub = frac_num * ov / d.res_den;
+                    const float frac = ((float)((frac_num * ov) % d.res_den)) / d.res_den;
+                    memcpy(&fbits, &frac, 4);
+                } else {
+                    sub = frac_num;
+                }
+                otab.push_back(make_uint2((uint32_t)pmod(pos - d.filt_len + 1, SR) | (sub << 24), fbits));
+            }
+        }
+        E = Eto;
+        cs.push_back(c);
+    }
+    int64_t launch_k0 = 0; // first output of the current launch (set by begin_launch)
+    // the first output the launch's waves may emit, relative to which k_off counts
+    int64_t begin_launch(const SliceRec &first) {
+        launch_k0 = d.resample ? E : first.K0;
+        return launch_k0;
+    }
+};
+
+// what one launch of the fused synthesis + overlap-add kernel needs from the host plan
+struct ChainLaunch {
+    const ChainSlice *slices; // [Tn] device
+    const float *wden, *wden_hi;
+    const uint2 *otab;
+    float *out;               // the row-0 address of the launch's first output
+};
+
 struct Core {
     Derived d;
     int device = 0, S = 0, C = 0, rows = 0;
@@ -120,6 +225,20 @@ struct Core {
     // persistent per-row phase state
     DevBuf<float> st_pp, st_po, st_rot;
     DevBuf<int32_t> st_kind;
+    // Fused synthesis + overlap-add ("chain", pv_kernels.h ChainArgs): the reference's accumulators live in LDS and
+    // their images are carried here between launches.  On by default (AUDIOMOD_PV_FUSED=0 selects the frame ring +
+    // tile kernel instead, which cannot represent dropped slices).
+    bool use_chain = false;
+    int chain_AR = 0, chain_SR = 0, chain_mirror = 0, chain_waves = 0;
+    int chain_max_adv = 0; // set before init(): the largest overlap-add advance the planner can emit
+    DevBuf<float> st_acc, st_str;
+    static bool chain_wanted() {
+        const char *e = getenv("AUDIOMOD_PV_FUSED");
+        if (e && atoi(e) == 0) return false;
+        const char *sl = getenv("AUDIOMOD_PV_STREAM_LAUNCHES"); // the opt-in one-workgroup streaming kernel chains
+        return !(sl && strcmp(sl, "single") == 0);               // the separate stages' device functions
+    }
+    bool wave_fft() const { return d.fft.nc == 1024 || d.fft.nc == 2048; }
 
     int init(const pv_config &cfg, int dev, int nstreams, int chunk_slices);
     int reset_state(hipStream_t st);
@@ -140,7 +259,8 @@ struct Core {
                       hipStream_t st, hipEvent_t *ev /* 2*PV_NUM_KERNELS events or null */, int part = 0,
                       hipStream_t st_chain = nullptr /* the chain's own stream (with ev_match / ev_chain) */,
                       hipEvent_t ev_match = nullptr, hipEvent_t ev_chain = nullptr,
-                      bool single_launch = false) const; // single_launch: the streaming path's one-workgroup kernel
+                      bool single_launch = false, // single_launch: the streaming path's one-workgroup kernel
+                      const struct ChainLaunch *chain = nullptr) const; // non-null: fused synthesis + overlap-add
     // Phase-locked batch path: the rotation chain of chunk i (one workgroup per row, a few waves, pure latency:
     // it leaves 95 % of the chip idle) runs on a second HIP stream while the main stream synthesises and
     // overlap-adds chunk i-1 and analyses and matches chunk i+1.  The slice-indexed planes then hold two chunks.
@@ -194,9 +314,46 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     otab_off = (ola_lds_floats + 3) & ~3;
     wacc_pitch = otab_off + 2 * kTileOut;
     lookback = (d.N + tile_span) / d.min_shift + 3;
-    if ((tile_span + d.N) / d.min_shift + 3 > kMaxTileFrames) {
+    use_chain = chain_wanted();
+    if (!use_chain && (tile_span + d.N) / d.min_shift + 3 > kMaxTileFrames) {
         g_last_error = "hop too small relative to the FFT size for the OLA tile";
         return PV_ERR_UNSUPPORTED;
+    }
+    if (use_chain) {
+        // ring sizes and waves per workgroup of the chain kernel: as many waves (slices of a row in flight) as LDS
+        // holds.  While a wave resamples slice t the others may finalise up to slice t + W - 1, and whole blocks of
+        // 64 outputs are deferred by up to one slice (ChainBuilder), so the stream ring keeps W advances plus one
+        // filter length plus the span of 64 outputs.
+        if (chain_max_adv <= 0) {
+            const bool fixed_shift = d.robotic || d.whisper || d.constant || d.vocoder;
+            double m = fixed_shift ? (double)d.hop : (d.int_ratio ? (double)d.hop * d.hs_ratio : 2.0 * d.hop * d.hs_ratio + 1);
+            chain_max_adv = (int)(m < d.N ? m + 1 : d.N);
+        }
+        chain_AR = d.N + 4;
+        chain_mirror = d.resample ? ((d.filt_len + 3) & ~3) : 4;
+        const int span64 = d.resample ? (int)((64ull * d.res_num + d.res_den - 1) / d.res_den) + 2 : 0;
+        const int wmax = d.fft.nc == 2048 ? 8 : 14;
+        ChainArgs probe{};
+        probe.AR = chain_AR;
+        probe.mirror = chain_mirror;
+        probe.tab_bytes = !d.resample ? 0
+                          : d.interp  ? d.oversample * (d.filt_len + 1) * 16
+                                      : (int)((d.sinc.size() * sizeof(float) + 15) & ~(size_t)15);
+        chain_waves = 0;
+        for (int w = wmax; w >= 1; --w) {
+            const int sr = (w * chain_max_adv + (d.resample ? d.filt_len : 0) + span64 + 8 + 3) & ~3;
+            probe.SR = sr;
+            probe.waves = w;
+            if (chain_lds_bytes(probe, wave_fft() ? d.fft.nc : 0) <= 160 * 1024 - 512) {
+                chain_waves = w;
+                chain_SR = sr;
+                break;
+            }
+        }
+        if (chain_waves == 0) {
+            g_last_error = "the overlap-add rings of this configuration do not fit the LDS";
+            return PV_ERR_UNSUPPORTED;
+        }
     }
     Tc = chunk_slices;
     // slice-indexed planes keep the last slice of the previous launch (pv_kernels.h); the pipelined batch path
@@ -287,7 +444,13 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     const size_t planes = (size_t)rows * TR;
     if ((st = mag.alloc(planes * HP)) != PV_OK) return st;
     if ((st = phase.alloc(planes * HP)) != PV_OK) return st;
-    if ((st = frames.alloc((size_t)rows * FR * d.N)) != PV_OK) return st;
+    if (use_chain) FR = next_pow2_i(Tc + 1); // the chain reads a launch's own frames only (and none at wave-FFT sizes)
+    if (!(use_chain && wave_fft()))
+        if ((st = frames.alloc((size_t)rows * FR * d.N)) != PV_OK) return st;
+    if (use_chain) {
+        if ((st = st_acc.alloc((size_t)rows * chain_AR)) != PV_OK) return st;
+        if ((st = st_str.alloc((size_t)rows * (chain_SR + chain_mirror))) != PV_OK) return st;
+    }
     const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder; // modes without a phase recurrence
     if (d.vocoder) {
         if ((st = cmag.alloc((size_t)TR * HP)) != PV_OK) return st;
@@ -314,6 +477,8 @@ int Core::reset_state(hipStream_t st) {
     if (st_pp.p) HIPC(hipMemsetAsync(st_pp.p, 0, st_pp.n * sizeof(float), st));
     if (st_po.p) HIPC(hipMemsetAsync(st_po.p, 0, st_po.n * sizeof(float), st));
     if (st_kind.p) HIPC(hipMemsetAsync(st_kind.p, 0, st_kind.n * sizeof(int32_t), st));
+    if (st_acc.p) HIPC(hipMemsetAsync(st_acc.p, 0, st_acc.n * sizeof(float), st));
+    if (st_str.p) HIPC(hipMemsetAsync(st_str.p, 0, st_str.n * sizeof(float), st));
     return PV_OK;
 }
 
@@ -322,7 +487,7 @@ bool Core::can_single_launch() const {
         const char *e = getenv("AUDIOMOD_PV_STREAM_LAUNCHES");
         return e && strcmp(e, "single") == 0;
     }();
-    if (!on || d.vocoder) return false;
+    if (!on || d.vocoder || use_chain) return false;
     StreamArgs probe{};
     probe.aa.tb = tb;
     probe.ma.hs = d.hs;
@@ -432,7 +597,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
                         int ntiles, const int64_t *d_P, const float *d_wacc, const float *d_whisper,
                         const InAddr *carrier, float *out, int64_t out_stride_row, int64_t k_base,
                         hipStream_t st, hipEvent_t *ev, int part, hipStream_t st_chain, hipEvent_t ev_match,
-                        hipEvent_t ev_chain, bool single_launch) const {
+                        hipEvent_t ev_chain, bool single_launch, const ChainLaunch *chain) const {
     const bool front = part != 2, back = part != 1;
     StreamArgs fused{};
     const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder;
@@ -608,6 +773,53 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         else if (back) launch_cepstral(ca, st);
         if (back) rec(2 * PV_K_CEPSTRAL + 1);
     }
+    if (chain && !single_launch) {
+        if (!back) return;
+        ChainArgs ca{};
+        ca.N = d.N;
+        ca.rows = rows;
+        ca.C = C;
+        ca.Tn = Tn;
+        ca.AR = chain_AR;
+        ca.SR = chain_SR;
+        ca.mirror = chain_mirror;
+        ca.waves = chain_waves;
+        ca.slices = chain->slices;
+        ca.wden = chain->wden;
+        ca.wden_hi = chain->wden_hi;
+        ca.otab = chain->otab;
+        ca.st_acc = st_acc.p;
+        ca.st_str = st_str.p;
+        ca.resample = d.resample ? 1 : 0;
+        ca.interp = d.interp ? 1 : 0;
+        ca.filt_len = d.filt_len;
+        ca.oversample = d.oversample;
+        ca.sinc = sinc.p;
+        ca.sinc_len = d.resample ? (int)d.sinc.size() : 0;
+        ca.tab4 = tab4.p;
+        ca.tab_bytes = !d.resample ? 0
+                       : d.interp  ? d.oversample * (d.filt_len + 1) * 16
+                                   : (int)((d.sinc.size() * sizeof(float) + 15) & ~(size_t)15);
+        ca.out = chain->out;
+        ca.out_stride_row = out_stride_row;
+        ca.frames = frames.p;
+        ca.FR = FR;
+        ca.t0 = t0;
+        if (wave_fft()) {
+            // synthesis, overlap-add and resampling in one kernel: the frames stay in LDS
+            rec(2 * PV_K_SYNTH_OLA);
+            launch_synth_chain(sa, ca, st);
+            rec(2 * PV_K_SYNTH_OLA + 1);
+        } else {
+            rec(2 * PV_K_SYNTH);
+            launch_synth(sa, st);
+            rec(2 * PV_K_SYNTH + 1);
+            rec(2 * PV_K_OLA_RESAMPLE);
+            launch_frames_chain(ca, st);
+            rec(2 * PV_K_OLA_RESAMPLE + 1);
+        }
+        return;
+    }
     if (back) rec(2 * PV_K_SYNTH);
     if (single_launch) fused.sa = sa;
     else if (back) launch_synth(sa, st);
@@ -690,7 +902,11 @@ struct pv_batch {
         int64_t t0;
         int Tn;
         int tile_begin, ntiles;
+        int64_t k0; // fused path: first output its waves emit
     };
+    DevBuf<ChainSlice> d_cs; // fused path: one entry per slice of the plan
+    DevBuf<float> d_wden, d_wden_hi;
+    DevBuf<uint2> d_otab;
     std::vector<Chunk> chunks;
     DevBuf<int32_t> d_pinc;
     DevBuf<int64_t> d_P;
@@ -718,7 +934,10 @@ struct pv_batch {
 
 struct pv_engine {
     Core core;
+    int poisoned = 0; // status of a failure that left device state and host bookkeeping out of step (sticky)
+    std::string poison_reason;
     std::unique_ptr<Planner> planner;
+    std::unique_ptr<ChainBuilder> chain; // fused path: the running host plan of the overlap-add rings
     std::vector<SliceRec> recent; // slice table window; recent[0] is slice t_base
     int64_t t_base = 0;
     int64_t fed = 0, uploaded = 0;
@@ -760,7 +979,7 @@ int pv_device_count(void) { return count_gfx950(); }
 const char *pv_kernel_name(int k) {
     static const char *n[PV_NUM_KERNELS] = {"pv_analyze_kernel", "pv_match_kernel", "pv_seq_kernel",
                                             "pv_prop_kernel",    "pv_synth_kernel", "pv_ola_kernel",
-                                            "pv_cepstral_kernel"};
+                                            "pv_cepstral_kernel", "pv_synth_ola_kernel"};
     return (k >= 0 && k < PV_NUM_KERNELS) ? n[k] : "";
 }
 
@@ -815,14 +1034,29 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
         if (v >= 4 && v <= 1024) Tc = v;
     }
     b->core.pipelined_planes = Core::pipeline_wanted(*cfg);
-    int st = b->core.init(*cfg, device, nstreams, Tc);
+    int st;
+    {
+        // the plan first: the overlap-add rings are sized from the advances it really contains
+        Derived dd;
+        if ((st = derive(*cfg, dd)) != PV_OK) return st;
+        if ((st = plan_batch(dd, frames, block, flush != 0, b->plan)) != PV_OK) return st;
+        int mx = 1;
+        for (const SliceRec &r : b->plan.slices) mx = r.adv > mx ? r.adv : mx;
+        b->core.chain_max_adv = mx;
+    }
+    st = b->core.init(*cfg, device, nstreams, Tc);
     if (st != PV_OK) return st;
     Core &c = b->core;
-    st = plan_batch(c.d, frames, block, flush != 0, b->plan);
-    if (st != PV_OK) return st;
     b->frames = frames;
     const auto &sl = b->plan.slices;
     const int64_t T = (int64_t)sl.size();
+    if (!c.use_chain)
+        for (const SliceRec &r : sl)
+            if (r.adv == 0) {
+                g_last_error = "more output pending than the reference's output ring holds (the reference drops "
+                               "slices there); only the fused overlap-add path reproduces that";
+                return PV_ERR_OUTPUT_OVERRUN;
+            }
     std::vector<int32_t> pinc((size_t)T);
     std::vector<int64_t> P((size_t)T);
     for (int64_t t = 0; t < T; ++t) {
@@ -831,17 +1065,25 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
     }
     std::vector<OlaTile> tiles;
     std::vector<float> wacc;
+    std::vector<ChainSlice> cs;
+    std::vector<float> wden, wden_hi;
+    std::vector<uint2> otab;
+    ChainBuilder cb(c.d, c.chain_AR, c.chain_SR);
     for (int64_t t0 = 0; t0 < T; t0 += Tc) {
         pv_batch::Chunk ch;
         ch.t0 = t0;
         ch.Tn = (int)((T - t0) < Tc ? (T - t0) : Tc);
+        ch.k0 = 0;
         const int64_t t1 = t0 + ch.Tn;
         int64_t ka = sl[(size_t)t0].K0;
         int64_t kb = sl[(size_t)(t1 - 1)].K0 + sl[(size_t)(t1 - 1)].cnt;
         if (ka > b->plan.out_frames) ka = b->plan.out_frames;
         if (kb > b->plan.out_frames) kb = b->plan.out_frames;
         ch.tile_begin = (int)tiles.size();
-        if (kb > ka) {
+        if (c.use_chain) {
+            ch.k0 = cb.begin_launch(sl[(size_t)t0]);
+            for (int64_t t = t0; t < t1; ++t) cb.add(sl[(size_t)t], t == t1 - 1, b->plan.out_frames, cs, wden, wden_hi, otab);
+        } else if (kb > ka) {
             st = c.build_tiles(sl, 0, t1, ka, kb, 0, tiles, wacc);
             if (st != PV_OK) return st;
         }
@@ -852,6 +1094,18 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
     if ((st = b->d_P.upload(P)) != PV_OK) return st;
     if ((st = b->d_tiles.upload(tiles)) != PV_OK) return st;
     if ((st = b->d_wacc.upload(wacc)) != PV_OK) return st;
+    if (c.use_chain) {
+        // (one spare entry each: a slice that finalises or emits nothing still prefetches its first entry)
+        wden.push_back(1.f);
+        wden_hi.push_back(1.f);
+        otab.push_back(make_uint2(0u, 0u));
+        if ((st = b->d_cs.upload(cs)) != PV_OK) return st;
+        if ((st = b->d_wden.upload(wden)) != PV_OK) return st;
+        if (cb.any_upper_skip) {
+            if ((st = b->d_wden_hi.upload(wden_hi)) != PV_OK) return st;
+        }
+        if ((st = b->d_otab.upload(otab)) != PV_OK) return st;
+    }
     if (c.can_overlap_chain()) {
         // highest stream priority: the dispatcher must place the chain's few workgroups ahead of the thousands
         // of overlap-add tiles queued on the main stream, or the chain only starts when the tiles are done
@@ -950,11 +1204,19 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
     };
     auto launch = [&](size_t ci, hipEvent_t *ev, int part) {
         const auto &ch = b->chunks[ci];
+        ChainLaunch cl{};
+        if (c.use_chain) {
+            cl.slices = b->d_cs.p + ch.t0;
+            cl.wden = b->d_wden.p;
+            cl.wden_hi = b->d_wden_hi.p ? b->d_wden_hi.p : b->d_wden.p;
+            cl.otab = b->d_otab.p;
+            cl.out = d_out + ch.k0;
+        }
         c.launch_chunk(ia, ch.t0, ch.Tn, b->d_pinc.p + ch.t0, b->d_tiles.p + ch.tile_begin, ch.ntiles, b->d_P.p,
                        b->d_wacc.p + (size_t)ch.tile_begin * c.wacc_pitch,
                        b->d_whisper.p ? b->d_whisper.p + (size_t)ch.t0 * c.C * c.HP : nullptr,
                        c.d.vocoder ? &car : nullptr, d_out, b->plan.out_frames, 0, st, ev, part, b->chain_stream,
-                       b->ev_match[ci & 3], b->ev_chain[ci & 3]);
+                       b->ev_match[ci & 3], b->ev_chain[ci & 3], false, c.use_chain ? &cl : nullptr);
     };
     const size_t nchunks = b->chunks.size();
     if (piped) {
@@ -985,7 +1247,10 @@ int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launch
             if ((k == PV_K_MATCH || k == PV_K_SEQ) && cm != 1) continue;
             if (k == PV_K_PROP && cm != 0) continue;
             if (k == PV_K_CEPSTRAL && !d.cepstral) continue;
-            if (k == PV_K_OLA_RESAMPLE) {
+            const bool fused = b->core.use_chain && b->core.wave_fft();
+            if (k == PV_K_SYNTH_OLA && !fused) continue;
+            if ((k == PV_K_SYNTH || k == PV_K_OLA_RESAMPLE) && fused) continue;
+            if (k == PV_K_OLA_RESAMPLE && !b->core.use_chain) {
                 const int ci2 = b->ev_chunk[i / kEvPerChunk];
                 if (b->chunks[(size_t)ci2].ntiles == 0) continue;
             }
@@ -1018,6 +1283,7 @@ int pv_create(const pv_config *cfg, int device, pv_engine **out) {
     if (st != PV_OK) return st;
     Core &c = e->core;
     e->planner.reset(new Planner(c.d));
+    if (c.use_chain) e->chain.reset(new ChainBuilder(c.d, c.chain_AR, c.chain_SR));
     HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->ring = next_pow2_i(3 * c.d.N + kStreamChunk * c.d.hop + 16);
     if ((st = e->d_in.alloc((size_t)c.C * e->ring)) != PV_OK) return st;
@@ -1032,7 +1298,7 @@ int pv_create(const pv_config *cfg, int device, pv_engine **out) {
     e->out_cap = (int)(kStreamChunk * per_slice) + 64;
     if ((st = e->d_out.alloc((size_t)c.C * e->out_cap)) != PV_OK) return st;
     if ((st = e->h_out.alloc((size_t)c.C * e->out_cap)) != PV_OK) return st;
-    const size_t desc_bytes = 256 * 1024;
+    const size_t desc_bytes = 256 * 1024; // grows on demand (ensure_desc)
     if ((st = e->d_desc.alloc(desc_bytes)) != PV_OK) return st;
     if ((st = e->h_desc.alloc(desc_bytes)) != PV_OK) return st;
     if (c.d.vocoder) {
@@ -1085,16 +1351,63 @@ static int upload_until(pv_engine *e, const float *const *in, int64_t call_base,
     return PV_OK;
 }
 
+// (re)size the pinned + device descriptor staging; contents are per launch group, nothing to preserve
+static int ensure_desc(pv_engine *e, size_t bytes) {
+    if (bytes <= e->h_desc.n) return PV_OK;
+    size_t cap = e->h_desc.n ? e->h_desc.n : 64 * 1024;
+    while (cap < bytes) cap *= 2;
+    HIPC(hipStreamSynchronize(e->stream)); // an earlier group's copy may still read the old buffer
+    int st = e->h_desc.alloc(cap);
+    if (st != PV_OK) return st;
+    return e->d_desc.alloc(cap);
+}
+static int ensure_out(pv_engine *e, int64_t cnt) {
+    if (cnt <= e->out_cap) return PV_OK;
+    int cap = e->out_cap;
+    while (cap < cnt) cap *= 2;
+    HIPC(hipStreamSynchronize(e->stream));
+    int st = e->d_out.alloc((size_t)e->core.C * cap);
+    if (st != PV_OK) return st;
+    if ((st = e->h_out.alloc((size_t)e->core.C * cap)) != PV_OK) return st;
+    e->out_cap = cap;
+    return PV_OK;
+}
+
 int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
     g_last_error.clear();
     plan_reason_clear();
     if (!e || n < 0 || (n > 0 && !in)) return PV_ERR_INVALID_ARG;
     Core &c = e->core;
+    if (e->poisoned) {
+        g_last_error = "engine unusable after an earlier failure inside pv_feed: " + e->poison_reason;
+        return e->poisoned;
+    }
     HIPC(hipSetDevice(c.device));
     const int64_t call_base = e->fed;
     std::vector<SliceRec> fresh;
+    // Planning is transactional: a call the planner refuses leaves the engine exactly where it was -- nothing fed,
+    // nothing pending -- so the caller may retrieve and try again.
+    const Planner::State before = e->planner->save();
     int st = e->planner->feed(n, fresh);
-    if (st != PV_OK) return st;
+    if (st == PV_OK && !c.use_chain)
+        for (const SliceRec &r : fresh)
+            if (r.adv == 0) {
+                g_last_error = "more output pending than the reference's output ring holds (the reference drops "
+                               "slices there): retrieve between calls, or use the fused overlap-add path";
+                st = PV_ERR_OUTPUT_OVERRUN;
+                break;
+            }
+    if (st != PV_OK) {
+        e->planner->restore(before);
+        return st;
+    }
+    // From here on device state and host bookkeeping move together; a failure in between (a HIP error) cannot be
+    // rolled back, so it makes the engine unusable instead of leaving it inconsistent.
+    auto fail = [&](int code) {
+        e->poisoned = code;
+        e->poison_reason = g_last_error.empty() ? pv_strerror(code) : g_last_error;
+        return code;
+    };
     e->fed += n;
     const int64_t t_new0 = e->t_base + (int64_t)e->recent.size();
     e->recent.insert(e->recent.end(), fresh.begin(), fresh.end());
@@ -1107,51 +1420,63 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         // overwritten while a previous async copy still reads it: groups are synchronised below.
         int64_t need = (tb - 1) * (int64_t)c.d.hop + c.d.N;
         if (need > e->fed) need = e->fed;
-        if ((st = upload_until(e, in, call_base, need)) != PV_OK) return st;
+        if ((st = upload_until(e, in, call_base, need)) != PV_OK) return fail(st);
 
-        // descriptors: [pinc Tn int32][P list int64][tiles]
         const SliceRec &first = e->recent[(size_t)(ta - e->t_base)];
         const SliceRec &last = e->recent[(size_t)(tb - 1 - e->t_base)];
         const int64_t ka = first.K0, kb = last.K0 + last.cnt;
+        if ((st = ensure_out(e, kb - ka)) != PV_OK) return fail(st);
+        // descriptors of the group, one upload: [pinc Tn int32] then either the tile path's [P list int64][tiles]
+        // [window sums + output tables] or the fused path's [ChainSlice Tn][denominators][output table]
         std::vector<OlaTile> tiles;
-        std::vector<float> wacc;
-        if (kb > ka) {
+        std::vector<float> wacc, wden, wden_hi;
+        std::vector<ChainSlice> cs;
+        std::vector<uint2> otab;
+        if (c.use_chain) {
+            e->chain->begin_launch(first);
+            for (int64_t t = ta; t < tb; ++t)
+                e->chain->add(e->recent[(size_t)(t - e->t_base)], t == tb - 1, INT64_MAX, cs, wden, wden_hi, otab);
+            wden.push_back(1.f);
+            wden_hi.push_back(1.f);
+            otab.push_back(make_uint2(0u, 0u));
+        } else if (kb > ka) {
             st = c.build_tiles(e->recent, e->t_base, tb, ka, kb, (int32_t)e->t_base, tiles, wacc);
-            if (st != PV_OK) return st;
+            if (st != PV_OK) return fail(st);
         }
-        if (kb - ka > e->out_cap) {
-            g_last_error = "internal: streaming output staging too small";
-            return PV_ERR_UNSUPPORTED;
-        }
+        auto pad16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        const size_t nP = c.use_chain ? 0 : (size_t)(tb - e->t_base);
+        const bool hi = c.use_chain && e->chain->any_upper_skip;
+        const size_t o_pinc = 0, o_a = pad16((size_t)Tn * 4);
+        const size_t o_b = o_a + (c.use_chain ? pad16(cs.size() * sizeof(ChainSlice)) : pad16(nP * 8));
+        const size_t o_c = o_b + (c.use_chain ? pad16(wden.size() * 4) : pad16(tiles.size() * sizeof(OlaTile)));
+        const size_t o_d = o_c + (c.use_chain ? (hi ? pad16(wden_hi.size() * 4) : 0) : pad16(wacc.size() * 4));
+        const size_t total = o_d + (c.use_chain ? pad16(otab.size() * sizeof(uint2)) : 0);
+        if ((st = ensure_desc(e, total)) != PV_OK) return fail(st);
         char *hd = e->h_desc.p;
-        size_t off = 0;
-        int32_t *h_pinc = reinterpret_cast<int32_t *>(hd + off);
+        int32_t *h_pinc = reinterpret_cast<int32_t *>(hd + o_pinc);
         for (int i = 0; i < Tn; ++i) h_pinc[i] = e->recent[(size_t)(ta + i - e->t_base)].phase_inc;
-        off += ((size_t)Tn * 4 + 15) & ~(size_t)15;
-        const size_t p_off_bytes = off;
-        int64_t *h_P = reinterpret_cast<int64_t *>(hd + off);
-        const size_t nP = (size_t)(tb - e->t_base);
-        for (size_t i = 0; i < nP; ++i) h_P[i] = e->recent[i].P;
-        off += (nP * 8 + 15) & ~(size_t)15;
-        const size_t t_off_bytes = off;
-        memcpy(hd + off, tiles.data(), tiles.size() * sizeof(OlaTile));
-        off += (tiles.size() * sizeof(OlaTile) + 15) & ~(size_t)15;
-        const size_t w_off_bytes = off;
-        if (off + wacc.size() * sizeof(float) <= e->h_desc.n) memcpy(hd + off, wacc.data(), wacc.size() * sizeof(float));
-        off += wacc.size() * sizeof(float);
-        if (off > e->h_desc.n) {
-            g_last_error = "internal: descriptor staging too small";
-            return PV_ERR_UNSUPPORTED;
+        if (c.use_chain) {
+            memcpy(hd + o_a, cs.data(), cs.size() * sizeof(ChainSlice));
+            memcpy(hd + o_b, wden.data(), wden.size() * 4);
+            if (hi) memcpy(hd + o_c, wden_hi.data(), wden_hi.size() * 4);
+            memcpy(hd + o_d, otab.data(), otab.size() * sizeof(uint2));
+        } else {
+            int64_t *h_P = reinterpret_cast<int64_t *>(hd + o_a);
+            for (size_t i = 0; i < nP; ++i) h_P[i] = e->recent[i].P;
+            memcpy(hd + o_b, tiles.data(), tiles.size() * sizeof(OlaTile));
+            memcpy(hd + o_c, wacc.data(), wacc.size() * sizeof(float));
         }
-        HIPC(hipMemcpyAsync(e->d_desc.p, hd, off, hipMemcpyHostToDevice, e->stream));
+        if (hipMemcpyAsync(e->d_desc.p, hd, total, hipMemcpyHostToDevice, e->stream) != hipSuccess)
+            return fail(hip_fail(hipGetLastError(), "descriptor upload", __LINE__));
 
         if (c.d.whisper) {
             for (int i = 0; i < Tn; ++i)
                 for (int ch = 0; ch < c.C; ++ch)
                     for (int k = 0; k <= c.d.hs; ++k)
                         e->h_whisper.p[((size_t)i * c.C + ch) * c.HP + k] = e->rng->next_phase();
-            HIPC(hipMemcpyAsync(e->d_whisper.p, e->h_whisper.p, (size_t)Tn * c.C * c.HP * sizeof(float),
-                                hipMemcpyHostToDevice, e->stream));
+            if (hipMemcpyAsync(e->d_whisper.p, e->h_whisper.p, (size_t)Tn * c.C * c.HP * sizeof(float),
+                               hipMemcpyHostToDevice, e->stream) != hipSuccess)
+                return fail(hip_fail(hipGetLastError(), "whisper upload", __LINE__));
         }
         InAddr ia;
         ia.in = e->d_in.p;
@@ -1163,20 +1488,29 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         car.in = e->d_carrier.p;
         car.stride_c = 0;
         car.stride_s = 0;
-        c.launch_chunk(ia, ta, Tn, reinterpret_cast<const int32_t *>(e->d_desc.p),
-                       reinterpret_cast<const OlaTile *>(e->d_desc.p + t_off_bytes), (int)tiles.size(),
-                       reinterpret_cast<const int64_t *>(e->d_desc.p + p_off_bytes),
-                       reinterpret_cast<const float *>(e->d_desc.p + w_off_bytes), e->d_whisper.p,
+        ChainLaunch cl{};
+        if (c.use_chain) {
+            cl.slices = reinterpret_cast<const ChainSlice *>(e->d_desc.p + o_a);
+            cl.wden = reinterpret_cast<const float *>(e->d_desc.p + o_b);
+            cl.wden_hi = hi ? reinterpret_cast<const float *>(e->d_desc.p + o_c) : cl.wden;
+            cl.otab = reinterpret_cast<const uint2 *>(e->d_desc.p + o_d);
+            cl.out = e->d_out.p;
+        }
+        c.launch_chunk(ia, ta, Tn, reinterpret_cast<const int32_t *>(e->d_desc.p + o_pinc),
+                       reinterpret_cast<const OlaTile *>(e->d_desc.p + o_b), (int)tiles.size(),
+                       reinterpret_cast<const int64_t *>(e->d_desc.p + o_a),
+                       reinterpret_cast<const float *>(e->d_desc.p + o_c), e->d_whisper.p,
                        c.d.vocoder ? &car : nullptr, e->d_out.p, e->out_cap, ka, e->stream, nullptr, 0, nullptr, nullptr,
-                       nullptr, c.can_single_launch());
-        (void)p_off_bytes;
+                       nullptr, c.can_single_launch(), c.use_chain ? &cl : nullptr);
         const int64_t cnt = kb - ka;
+        hipError_t he = hipSuccess;
         if (cnt > 0)
-            HIPC(hipMemcpy2DAsync(e->h_out.p, (size_t)e->out_cap * sizeof(float), e->d_out.p,
+            he = hipMemcpy2DAsync(e->h_out.p, (size_t)e->out_cap * sizeof(float), e->d_out.p,
                                   (size_t)e->out_cap * sizeof(float), (size_t)cnt * sizeof(float), (size_t)c.C,
-                                  hipMemcpyDeviceToHost, e->stream));
-        HIPC(hipStreamSynchronize(e->stream));
-        HIPC(hipGetLastError());
+                                  hipMemcpyDeviceToHost, e->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        if (he == hipSuccess) he = hipGetLastError();
+        if (he != hipSuccess) return fail(hip_fail(he, "streaming launch group", __LINE__));
         for (int ch = 0; ch < c.C && cnt > 0; ++ch) {
             const float *src = e->h_out.p + (size_t)ch * e->out_cap;
             e->outq[(size_t)ch].insert(e->outq[(size_t)ch].end(), src, src + cnt);
@@ -1189,13 +1523,17 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         }
     }
     // everything fed stays needed by later slices (at most 2N unconsumed): park it in the device ring
-    if ((st = upload_until(e, in, call_base, e->fed)) != PV_OK) return st;
-    HIPC(hipStreamSynchronize(e->stream));
+    if ((st = upload_until(e, in, call_base, e->fed)) != PV_OK) return fail(st);
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "stream sync", __LINE__));
     return PV_OK;
 }
 
 int32_t pv_retrieve(pv_engine *e, float *const *out, int32_t n) {
     if (!e || n < 0 || (n > 0 && !out)) return -1;
+    // never hand out more than the FIFO holds (the planner's count and the FIFO move together; this is the guard
+    // against that invariant ever breaking, not a normal path)
+    const size_t held = e->outq.empty() ? 0 : e->outq[0].size() - e->outq_head;
+    if ((size_t)n > held) n = (int32_t)held;
     const int32_t got = e->planner->retrieve(n);
     for (int ch = 0; ch < e->core.C; ++ch) {
         const std::vector<float> &q = e->outq[(size_t)ch];

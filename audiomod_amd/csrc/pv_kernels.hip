@@ -1049,8 +1049,12 @@ __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a
 // synthesis, wave-per-frame variant.  The wave-private LDS region is reused four times:
 // [output phases + rot/peak lists] -> [spectrum X] -> [butterfly-ordered input] -> [time-domain frame].
 // --------------------------------------------------------------------------------------------
-template <int NC, int kPlainCore = -1>
-__device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int row, const int tl, cf *lds) {
+// kSink: 0 = the windowed frame goes to the HBM frame ring (a.frames); 1 = the un-windowed, un-shifted time-domain
+// frame stays in the wave's LDS region (element e at lds[W::pad(e)] = samples 2e, 2e + 1) for the fused
+// overlap-add that follows in the same kernel (pv_synth_chain_kernel)
+template <int NC, int kPlainCore = -1, int kSink = 0>
+__device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int row, const int tl, cf *lds,
+                                                const int lane_in = -1) {
     // kPlainCore >= 0: the plain pitch shift / stretch in that core mode (no frequency compression, vocoder,
     // robotic, whisper or pass-through source): the mode switches fold away, the kernel is half the code
     SynthArgs a = a_in;
@@ -1060,7 +1064,9 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
     }
     using W = WF<NC>;
     constexpr int N = 2 * NC, hs = NC, R = W::R;
-    const int lane = threadIdx.x & 63;
+    // (a caller that loops over slices passes a lane id that is opaque per iteration, so that the lane-dependent
+    // addresses and constants below are not hoisted out of its loop and kept in registers across iterations)
+    const int lane = lane_in >= 0 ? lane_in : (int)(threadIdx.x & 63);
     const DevTables &tb = a.tb;
     const int64_t t = a.t0 + tl;
     const int64_t plane = (int64_t)row * a.TR + ring_slot(a.s0, tl, a.TR);
@@ -1347,6 +1353,11 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
         wf_load<W, 2>(lds, v, lp2);
         wf_unpack_pass_tw<W, 2>(T2, raw2);
         wf_apply_pass_stages<W, 2, true>(v, T2);
+        if constexpr (kSink == 1) {
+            wf_store<W, 2>(lds, v, lp2);
+            wave_sync();
+            return;
+        }
         float4 ww[NC / 128];
 #pragma unroll
         for (int j = 0; j < NC / 128; ++j) ww[j] = *reinterpret_cast<const float4 *>(w + 4 * (lane + 64 * j));
@@ -1380,6 +1391,10 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
             wf_fetch_pass_tw<W, 2>(r2, lane, twl);
             wf_unpack_pass_tw<W, 2>(T2, r2);
             wf_fft_pass_tw<W, 2, true>(v, lane, lds, T2);
+        }
+        if constexpr (kSink == 1) {
+            wave_sync();
+            return;
         }
         // (v is dead now: the whole window fits in its registers, fetched before the frame's first store, and the
         // frame leaves 16 bytes per lane like the other variant's)
@@ -1887,6 +1902,371 @@ void launch_ola(const OlaArgs &a, hipStream_t st) {
     } else {
         allow_big_lds(pv_ola_kernel<2>, big2);
         hipLaunchKernelGGL(pv_ola_kernel<2>, grid, dim3(kTileOut), lds, st, a);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Fused synthesis + overlap-add + resample (pv_kernels.h ChainArgs): the reference's streaming state kept in LDS.
+//
+//   synthesiseSlice (:1057,1073):  outputAccumulator[0..N) += frame         -> acc ring, frame t at P_t
+//   writeSlice (:1157-1194):       acc[0..s) /= wacc[0..s); resample or ring-write; shift both by s
+//                                  -> finalise [P_t, P_t + s): divide by the host-planned window sum (the
+//                                     denominator is data-independent), append to the stream ring, zero the slots
+//   resampler_basic_interpolate_single / _direct_single (speex/resample.c:462-560, 353-401)
+//                                  -> every output whose window the stream ring now holds
+//
+// One workgroup per row; wave w owns slices w, w + W, ...: it synthesises its frame into its LDS region (or takes
+// the windowed frame from the HBM frame ring), waits for its turn, adds the frame, finalises, passes the turn on,
+// and resamples outside the turn.  Adds happen strictly in slice order, so every accumulator sample sees the
+// reference's sequence of float additions; a dropped slice (adv == 0) simply leaves its frame piled where it is.
+// There is no workgroup barrier inside the loop: waves drift apart and hide each other's latencies, the turn
+// counter only serialises the few hundred cycles of the add.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_ror1(float v) { // lane i <- lane i - 1, lane 0 <- lane 63
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xf, 0xf, false));
+}
+
+struct ChainLds {
+    float *acc;   // [AR]
+    float *str;   // [SR + mirror]
+    char *tab;    // resampler coefficients
+    int *turn;    // next slice whose frame may be added
+};
+__device__ __forceinline__ ChainLds chain_carve(const ChainArgs &c, char *base) {
+    ChainLds l;
+    l.tab = base;
+    l.acc = reinterpret_cast<float *>(base + c.tab_bytes);
+    l.str = l.acc + c.AR;
+    l.turn = reinterpret_cast<int *>(l.str + c.SR + c.mirror);
+    return l;
+}
+__host__ __device__ inline size_t chain_shared_bytes(const ChainArgs &c) {
+    return (size_t)c.tab_bytes + sizeof(float) * ((size_t)c.AR + c.SR + c.mirror) + 16;
+}
+
+// ring images and coefficient table in, before the first slice (whole workgroup)
+__device__ __forceinline__ void chain_prologue(const ChainArgs &c, const ChainLds &l, int row) {
+    const int nt = blockDim.x, tid = threadIdx.x;
+    const float4 *sa = reinterpret_cast<const float4 *>(c.st_acc + (int64_t)row * c.AR);
+    for (int i = tid; i < c.AR / 4; i += nt) reinterpret_cast<float4 *>(l.acc)[i] = sa[i];
+    const int sn = (c.SR + c.mirror) / 4;
+    const float4 *ss = reinterpret_cast<const float4 *>(c.st_str + (int64_t)row * (c.SR + c.mirror));
+    for (int i = tid; i < sn; i += nt) reinterpret_cast<float4 *>(l.str)[i] = ss[i];
+    if (c.resample) {
+        if (c.interp) {
+            const int cnt = c.oversample * (c.filt_len + 1);
+            for (int i = tid; i < cnt; i += nt) reinterpret_cast<float4 *>(l.tab)[i] = c.tab4[i];
+        } else {
+            for (int i = tid; i < c.sinc_len; i += nt) reinterpret_cast<float *>(l.tab)[i] = c.sinc[i];
+        }
+    }
+    if (tid == 0) *l.turn = 0;
+    __syncthreads();
+}
+__device__ __forceinline__ void chain_epilogue(const ChainArgs &c, const ChainLds &l, int row) {
+    __syncthreads(); // every wave has passed its last turn and finished reading the stream ring
+    const int nt = blockDim.x, tid = threadIdx.x;
+    float4 *sa = reinterpret_cast<float4 *>(c.st_acc + (int64_t)row * c.AR);
+    for (int i = tid; i < c.AR / 4; i += nt) sa[i] = reinterpret_cast<const float4 *>(l.acc)[i];
+    const int sn = (c.SR + c.mirror) / 4;
+    float4 *ss = reinterpret_cast<float4 *>(c.st_str + (int64_t)row * (c.SR + c.mirror));
+    for (int i = tid; i < sn; i += nt) ss[i] = reinterpret_cast<const float4 *>(l.str)[i];
+}
+
+// What a wave fetches for its slice before it waits for its turn: the first 256 denominators and output-table
+// entries (the rest, for hops above 256 samples, are read in the loops).
+struct ChainPrefetch {
+    float wd[4];
+    uint2 oe[4];
+};
+__device__ __forceinline__ void chain_prefetch(const ChainArgs &c, const ChainSlice &sl, int row, int lane,
+                                               ChainPrefetch &pf) {
+    const float *__restrict__ wden = (row % c.C) > 0 ? c.wden_hi : c.wden;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int i = lane + 64 * m;
+        pf.wd[m] = wden[sl.wden_off + (i < sl.adv ? i : 0)];
+        pf.oe[m] = c.resample ? c.otab[sl.otab_off + (i < sl.kcnt ? i : 0)] : make_uint2(0u, 0u);
+    }
+}
+
+__device__ __forceinline__ void chain_wait_turn(int *turn, int tl) {
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != tl)
+        __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ void chain_pass_turn(int *turn, int tl, int lane) {
+    // LDS only: the wave's outstanding global loads and stores are none of the next wave's business
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (lane == 0) __hip_atomic_store(turn, tl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Add NP pieces of a frame (piece j = this lane's four windowed samples 4 (lane + 64 (j0 + j)) .. + 3, zeros past the
+// frame's end) into the accumulator ring.  The ring is updated in aligned quads: a frame that starts r = R_ samples
+// into a quad is shifted by r through the neighbouring lane (DPP rotate; lane 0 takes lane 63 of the previous
+// piece, carried in prevR between calls).  Positions outside the frame receive +0.0f, which leaves any sum that
+// started from +0.0f as it is.  `last`: also the quad that holds the frame's final r samples.
+template <int R_, int NP>
+__device__ __forceinline__ void chain_add_pieces(float *acc, const int AQ, const int a, const int NQ, const int lane,
+                                                 const int j0, const float4 (&A)[NP], float4 &prevR, const bool last) {
+    float4 *acc4 = reinterpret_cast<float4 *>(acc);
+    const int qend = NQ + (R_ ? 1 : 0); // quads the frame touches
+    auto step = [&](const int u, const float4 Aj) {
+        float4 S = Aj;
+        if (R_ != 0) {
+            const float4 Rr = make_float4(dpp_ror1(Aj.x), dpp_ror1(Aj.y), dpp_ror1(Aj.z), dpp_ror1(Aj.w));
+            const float4 P = lane == 0 ? prevR : Rr;
+            prevR = Rr;
+            if (R_ == 1) S = make_float4(P.w, Aj.x, Aj.y, Aj.z);
+            else if (R_ == 2) S = make_float4(P.z, P.w, Aj.x, Aj.y);
+            else S = make_float4(P.y, P.z, P.w, Aj.x);
+        }
+        if (u < qend) {
+            int q = a + u;
+            if (q >= AQ) q -= AQ;
+            float4 v = acc4[q];
+            v.x += S.x, v.y += S.y, v.z += S.z, v.w += S.w;
+            acc4[q] = v;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < NP; ++j) step(lane + 64 * (j0 + j), A[j]);
+    // the quad behind the frame's last full one takes its final r samples (when the pieces end exactly there)
+    if (R_ != 0 && last) step(lane + 64 * (j0 + NP), make_float4(0.f, 0.f, 0.f, 0.f));
+}
+template <int NP>
+__device__ __forceinline__ void chain_add_dispatch(float *acc, int AR, int acc_pos, int NQ, int lane, int j0,
+                                                   const float4 (&A)[NP], float4 &prevR, bool last) {
+    const int r = acc_pos & 3, AQ = AR >> 2, a = acc_pos >> 2; // r is wave-uniform
+    if (r == 0) chain_add_pieces<0, NP>(acc, AQ, a, NQ, lane, j0, A, prevR, last);
+    else if (r == 1) chain_add_pieces<1, NP>(acc, AQ, a, NQ, lane, j0, A, prevR, last);
+    else if (r == 2) chain_add_pieces<2, NP>(acc, AQ, a, NQ, lane, j0, A, prevR, last);
+    else chain_add_pieces<3, NP>(acc, AQ, a, NQ, lane, j0, A, prevR, last);
+}
+
+template <int kRes> // -1 = from the arguments, 0 = none, 1 = direct sinc table, 2 = cubic-interpolated table
+__device__ __forceinline__ void chain_finish_slice(const ChainArgs &c_in, const ChainLds &l, const ChainSlice &sl,
+                                                   const ChainPrefetch &pf, const int row, const int tl, const int lane) {
+    ChainArgs c = c_in;
+    if (kRes >= 0) c.resample = kRes != 0, c.interp = kRes == 2;
+    // ---- finalise [P_t, P_t + adv): acc / window sum -> stream ring (or straight out when nothing resamples)
+    const float *__restrict__ wden = (row % c.C) > 0 ? c.wden_hi : c.wden;
+    float *__restrict__ out = c.out + (int64_t)row * c.out_stride_row + sl.k_off;
+    auto finalise = [&](int i, float wd) {
+        int ai = sl.acc_pos + i;
+        if (ai >= c.AR) ai -= c.AR;
+        const float v = l.acc[ai];
+        l.acc[ai] = 0.f;
+        const float y = v / wd;
+        if (c.resample) {
+            int si = sl.str_pos + i;
+            if (si >= c.SR) si -= c.SR;
+            l.str[si] = y;
+            if (si < c.mirror) l.str[si + c.SR] = y;
+        } else if (i < sl.kcnt) {
+            out[i] = y;
+        }
+    };
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int i = lane + 64 * m;
+        if (i < sl.adv) finalise(i, pf.wd[m]);
+    }
+    for (int i = 256 + lane; i < sl.adv; i += 64) finalise(i, wden[sl.wden_off + i]);
+    // ---- the next frame may be added now
+    chain_pass_turn(l.turn, tl, lane);
+    if (!c.resample) return;
+    // ---- resample, outside the turn; a window is one linear run of the stream ring thanks to the mirror
+    const int NF = c.filt_len;
+    auto resample_one = [&](int o, uint2 oe) {
+        const float *x = l.str + (oe.x & 0xffffffu);
+        const int sub = (int)(oe.x >> 24);
+        if (c.interp) {
+            const float frac = __uint_as_float(oe.y);
+            const float4 *__restrict__ T = reinterpret_cast<const float4 *>(l.tab) + sub * (NF + 1);
+            v2f a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll 4
+            for (int j = 0; j < NF; ++j) { // NF is a multiple of 4 (resample.c:687)
+                const float4 cc = T[j];
+                const v2f c01 = {cc.x, cc.y}, c23 = {cc.z, cc.w};
+                const float xv = x[j];
+                const v2f xx = {xv, xv};
+                a01 += xx * c01; // -ffp-contract=off: separate multiply and add, like the reference
+                a23 += xx * c23;
+            }
+            // cubic_coef (resample.c:339-351)
+            const float c0 = -0.16667f * frac + 0.16667f * frac * frac * frac;
+            const float c1 = frac + 0.5f * frac * frac - 0.5f * frac * frac * frac;
+            const float c3 = -0.33333f * frac + 0.5f * frac * frac - 0.16667f * frac * frac * frac;
+            const float c2 = (float)(1. - c0 - c1 - c3);
+            out[o] = (c0 * a01.x) + (c1 * a01.y) + (c2 * a23.x) + (c3 * a23.y);
+        } else {
+            const float *t = reinterpret_cast<const float *>(l.tab) + sub * NF;
+            float sum = 0.f;
+            for (int j = 0; j < NF; ++j) sum += x[j] * t[j];
+            out[o] = sum;
+        }
+    };
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int o = lane + 64 * m;
+        if (64 * m < sl.kcnt) { // wave-uniform
+            if (o < sl.kcnt) resample_one(o, pf.oe[m]);
+        }
+    }
+    for (int o = 256 + lane; o < sl.kcnt; o += 64) resample_one(o, c.otab[sl.otab_off + o]);
+}
+
+template <int NC, int kPlainCore, int kRes>
+__global__ __launch_bounds__(NC == 1024 ? 896 : 512) void pv_synth_chain_kernel(const SynthArgs s, const ChainArgs c) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    using W = WF<NC>;
+    constexpr int N = 2 * NC, hs = NC, NQ = N / 4, NP = NQ / 64;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int row = blockIdx.x;
+    cf *wlds = reinterpret_cast<cf *>(smem_raw) + wave * W::LDS_CF;
+    const ChainLds l = chain_carve(c, smem_raw + (size_t)c.waves * W::LDS_CF * sizeof(cf));
+    chain_prologue(c, l, row);
+    const float *__restrict__ w = s.tb.window;
+    const bool upper = (row % c.C) > 0;
+    const int lane0 = lane;
+    for (int tl = wave; tl < c.Tn; tl += c.waves) {
+        // the lane id, made opaque once per iteration: everything derived from it is recomputed per slice instead of
+        // being hoisted out of the loop and held in registers (which spilled ~100 VGPRs)
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const ChainSlice sl = c.slices[tl];
+        const bool skip = (sl.flags & 1) && upper; // wave-uniform
+        float4 A[NP];
+        if (!skip) {
+            synth_wave_role<NC, kPlainCore, 1>(s, row, tl, wlds, lane);
+            // ifftshift + synthesis window (phasevocoderimpl.h:183-198): four consecutive samples per lane and piece
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int i = 4 * (lane + 64 * j);
+                const int e = ((i + hs) & (N - 1)) >> 1;
+                const cf z0 = wlds[W::pad(e)], z1 = wlds[W::pad(e) + 1];
+                const float4 ww = *reinterpret_cast<const float4 *>(w + i);
+                A[j] = make_float4(z0.x * ww.x, z0.y * ww.y, z1.x * ww.z, z1.y * ww.w);
+            }
+        }
+        ChainPrefetch pf;
+        chain_prefetch(c, sl, row, lane, pf);
+        chain_wait_turn(l.turn, tl);
+        if (!skip) {
+            float4 prevR = make_float4(0.f, 0.f, 0.f, 0.f);
+            chain_add_dispatch<NP>(l.acc, c.AR, sl.acc_pos, NQ, lane, 0, A, prevR, true);
+            wave_sync();
+        }
+        chain_finish_slice<kRes>(c, l, sl, pf, row, tl, lane);
+    }
+    chain_epilogue(c, l, row);
+}
+
+// Any FFT size: the synthesis kernel has written the windowed frames to the HBM frame ring; the chain takes them
+// from there, up to eight pieces (2048 samples) at a time.
+template <int kRes> __global__ __launch_bounds__(896) void pv_frames_chain_kernel(const ChainArgs c) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int row = blockIdx.x;
+    const ChainLds l = chain_carve(c, smem_raw);
+    chain_prologue(c, l, row);
+    const int NQ = c.N >> 2;
+    const int groups = (NQ + 511) >> 9;
+    const bool upper = (row % c.C) > 0;
+    for (int tl = wave; tl < c.Tn; tl += c.waves) {
+        const ChainSlice sl = c.slices[tl];
+        const bool skip = (sl.flags & 1) && upper;
+        ChainPrefetch pf;
+        chain_prefetch(c, sl, row, lane, pf);
+        const int fslot = (int)((c.t0 + tl) & (int64_t)(c.FR - 1));
+        const float4 *__restrict__ fr =
+            reinterpret_cast<const float4 *>(c.frames + ((int64_t)row * c.FR + fslot) * c.N);
+        auto load_group = [&](int g, float4 (&A)[8]) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int u = lane + 64 * (8 * g + j);
+                A[j] = (u < NQ && !skip) ? fr[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        float4 A[8];
+        load_group(0, A);
+        chain_wait_turn(l.turn, tl);
+        if (!skip) {
+            float4 prevR = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g = 0; g < groups; ++g) {
+                if (g > 0) load_group(g, A);
+                chain_add_dispatch<8>(l.acc, c.AR, sl.acc_pos, NQ, lane, 8 * g, A, prevR, g == groups - 1);
+            }
+            wave_sync();
+        }
+        chain_finish_slice<kRes>(c, l, sl, pf, row, tl, lane);
+    }
+    chain_epilogue(c, l, row);
+}
+
+size_t chain_lds_bytes(const ChainArgs &a, int nc_wave) {
+    const size_t per_wave = nc_wave == 1024 ? WF<1024>::LDS_CF * sizeof(cf)
+                            : nc_wave == 2048 ? WF<2048>::LDS_CF * sizeof(cf) : 0;
+    return (size_t)a.waves * per_wave + chain_shared_bytes(a);
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel AND device
+template <typename K> static void allow_big_lds_dev(K kernel, unsigned long long &done_mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(&done_mask, __ATOMIC_ACQUIRE) & bit) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024 - 512);
+    __atomic_fetch_or(&done_mask, bit, __ATOMIC_RELEASE);
+}
+
+template <int NC, int kPlainCore> static void launch_synth_chain_res(const SynthArgs &s, const ChainArgs &c, hipStream_t st) {
+    const size_t lds = chain_lds_bytes(c, NC);
+    const dim3 grid(c.rows), block(64 * c.waves);
+    static unsigned long long m0 = 0, m1 = 0, m2 = 0;
+    if (!c.resample) {
+        allow_big_lds_dev(pv_synth_chain_kernel<NC, kPlainCore, 0>, m0);
+        hipLaunchKernelGGL((pv_synth_chain_kernel<NC, kPlainCore, 0>), grid, block, lds, st, s, c);
+    } else if (!c.interp) {
+        allow_big_lds_dev(pv_synth_chain_kernel<NC, kPlainCore, 1>, m1);
+        hipLaunchKernelGGL((pv_synth_chain_kernel<NC, kPlainCore, 1>), grid, block, lds, st, s, c);
+    } else {
+        allow_big_lds_dev(pv_synth_chain_kernel<NC, kPlainCore, 2>, m2);
+        hipLaunchKernelGGL((pv_synth_chain_kernel<NC, kPlainCore, 2>), grid, block, lds, st, s, c);
+    }
+}
+
+void launch_synth_chain(const SynthArgs &s, const ChainArgs &c, hipStream_t st) {
+    const bool plain = !s.do_freq_comp && s.voc_band_len < 0 && !s.robotic && !s.passthru && !s.whisper &&
+                       !synth_generic_only() && s.coremode >= 0 && s.coremode <= 2;
+    if (s.tb.nc == 1024) {
+        if (plain && s.coremode == 1) launch_synth_chain_res<1024, 1>(s, c, st);
+        else if (plain && s.coremode == 0) launch_synth_chain_res<1024, 0>(s, c, st);
+        else if (plain) launch_synth_chain_res<1024, 2>(s, c, st);
+        else launch_synth_chain_res<1024, -1>(s, c, st);
+    } else {
+        if (plain && s.coremode == 1) launch_synth_chain_res<2048, 1>(s, c, st);
+        else if (plain && s.coremode == 0) launch_synth_chain_res<2048, 0>(s, c, st);
+        else if (plain) launch_synth_chain_res<2048, 2>(s, c, st);
+        else launch_synth_chain_res<2048, -1>(s, c, st);
+    }
+}
+
+void launch_frames_chain(const ChainArgs &c, hipStream_t st) {
+    const size_t lds = chain_lds_bytes(c, 0);
+    const dim3 grid(c.rows), block(64 * c.waves);
+    static unsigned long long m0 = 0, m1 = 0, m2 = 0;
+    if (!c.resample) {
+        allow_big_lds_dev(pv_frames_chain_kernel<0>, m0);
+        hipLaunchKernelGGL(pv_frames_chain_kernel<0>, grid, block, lds, st, c);
+    } else if (!c.interp) {
+        allow_big_lds_dev(pv_frames_chain_kernel<1>, m1);
+        hipLaunchKernelGGL(pv_frames_chain_kernel<1>, grid, block, lds, st, c);
+    } else {
+        allow_big_lds_dev(pv_frames_chain_kernel<2>, m2);
+        hipLaunchKernelGGL(pv_frames_chain_kernel<2>, grid, block, lds, st, c);
     }
 }
 

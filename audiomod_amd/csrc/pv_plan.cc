@@ -356,6 +356,25 @@ int Planner::try_slice(std::vector<SliceRec> &out) {
     r.phase_inc = (int32_t)phaseInc;
     r.P = P_;
     r.K0 = K_;
+    r.adv = (int32_t)shiftInc;
+    r.flags = 0;
+    // output-ring guard (phasevocoderprocess.cc:337-364; CONSTANT :139-150; vocoder :1203-1212).  All channels hold
+    // the same amount, so they decide alike.  A slice that finds the ring too full is DROPPED, not refused: its frame
+    // is already in the accumulators, writeSlice does not run, nothing is emitted and nothing shifts -- the following
+    // frames pile up on the same overlap-add position until the caller has retrieved enough.
+    {
+        const int required = (d_.constant || d_.vocoder) ? d_.hop : int(shiftInc / d_.pitch_scale) + 1;
+        const int64_t ws = d_.outbuf_cap - out_fill_;
+        if (ws < required) {
+            r.adv = 0;
+            r.cnt = 0;
+            if (d_.constant) r.flags |= kSliceUpperChannelsSkip;
+            ++slices_;
+            ++dropped_;
+            out.push_back(r);
+            return PV_OK;
+        }
+    }
     const int64_t Pn = P_ + (int64_t)shiftInc;
     int64_t Kn;
     if (d_.resample) {
@@ -370,17 +389,6 @@ int Planner::try_slice(std::vector<SliceRec> &out) {
         Kn = Pn;
     }
     r.cnt = (int32_t)(Kn - K_);
-    // output-ring guard (phasevocoderprocess.cc:337-364)
-    int required = (d_.constant || d_.vocoder) ? d_.hop : int(shiftInc / d_.pitch_scale) + 1; // :142, :1203 vs :337
-    int64_t ws = d_.outbuf_cap - out_fill_;
-    if (ws < required) {
-        // The reference drops the slice here (processSliceForChannel :337-364: frame already added into the
-        // accumulators, writeSlice skipped, so the following frames pile up on the same overlap-add position; the
-        // CONSTANT loop even returns mid-way, leaving the channels in different states).  A run of dropped slices is
-        // unbounded, the frame ring is not: refused, loudly, instead of reproduced.
-        g_plan_reason = "more output pending than the reference's output ring holds: retrieve between calls";
-        return PV_ERR_OUTPUT_OVERRUN;
-    }
     out_fill_ += r.cnt;
     P_ = Pn;
     K_ = Kn;

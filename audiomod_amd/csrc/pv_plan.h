@@ -73,10 +73,16 @@ int derive(const pv_config &cfg, Derived &d);
 struct SliceRec {
     int32_t shift;     // shiftIncrement s_t
     int32_t phase_inc; // phaseIncrement
-    int64_t P;         // OLA-stream position of this slice's frame = sum of previous shifts
+    int64_t P;         // OLA-stream position of this slice's frame = sum of the advances before it
     int64_t K0;        // outputs emitted before this slice
     int32_t cnt;       // outputs emitted by this slice
+    int32_t adv;       // how far the OLA stream advances after this slice: its shift, or 0 when the reference finds its
+                       // output ring too full and drops the slice (phasevocoderprocess.cc:337-364): the frame has been
+                       // added to the accumulators, writeSlice is skipped, the next frame lands on the same position
+    int32_t flags;     // kSliceUpperChannelsSkip: CONSTANT mode returns from its channel loop at the first full ring
+                       // (processOneSliceConstant :139-150), so only channel 0 has added this slice's frame
 };
+enum : int32_t { kSliceUpperChannelsSkip = 1 };
 
 // Integer simulation of the reference's ring occupancy and increment recurrences.
 // why the planner last refused something (thread-local static text, "" if it has not); cleared by the C-ABI entry
@@ -97,14 +103,28 @@ class Planner {
         return g;
     }
     int64_t slices() const { return slices_; }
+    int64_t dropped() const { return dropped_; } // slices the reference would have dropped so far
     int64_t outputs() const { return K_; }
     int64_t ola_len() const { return P_; }
+    // The whole mutable state, so that a caller can make feed() transactional: save, feed, and put the state back
+    // when anything about the call fails (pv_feed: the engine then stays exactly where it was).
+    struct State {
+        int64_t in_fill, out_fill, slices, dropped, K, P, prev_increment;
+        float recovery, divergence;
+    };
+    State save() const {
+        return State{in_fill_, out_fill_, slices_, dropped_, K_, P_, prev_increment_, recovery_, divergence_};
+    }
+    void restore(const State &s) {
+        in_fill_ = s.in_fill, out_fill_ = s.out_fill, slices_ = s.slices, dropped_ = s.dropped, K_ = s.K, P_ = s.P;
+        prev_increment_ = s.prev_increment, recovery_ = s.recovery, divergence_ = s.divergence;
+    }
 
   private:
     int try_slice(std::vector<SliceRec> &out);
     int next_increment();
     const Derived &d_;
-    int64_t in_fill_ = 0, out_fill_ = 0, slices_ = 0, K_ = 0, P_ = 0;
+    int64_t in_fill_ = 0, out_fill_ = 0, slices_ = 0, dropped_ = 0, K_ = 0, P_ = 0;
     float recovery_ = 0, divergence_ = 0;
     int64_t prev_increment_ = 0;
 };

@@ -25,7 +25,7 @@ VOCODER_ROSENBERG, VOCODER_CHORD, NORMAL_STRETCH, ROBOTIC, WHISPER = 3, 4, 5, 6,
 FORMANT_CEPSTRAL = 8
 NORMAL_PV, PHASE_LOCKED, INT_RATIO = 0, 1, 2
 KERNELS = ("pv_analyze_kernel", "pv_match_kernel", "pv_seq_kernel", "pv_prop_kernel", "pv_synth_kernel",
-           "pv_ola_kernel", "pv_cepstral_kernel")
+           "pv_ola_kernel", "pv_cepstral_kernel", "pv_synth_ola_kernel")
 
 
 class PvError(RuntimeError):

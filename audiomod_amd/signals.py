@@ -61,3 +61,38 @@ def dual_mono(frames, seed=1234, sample_rate=48000):
     """L == R: pins the reference's cross-channel state sharing."""
     m = voice(frames, 1, seed, sample_rate)
     return np.concatenate([m, m], axis=0)
+
+
+def synthetic_batch(torch, streams, frames, device, rank=0, channels=2, duplicates=()):
+    """[streams, channels, frames] float32 on `device`, on the int16 grid: a few host-synthesised voices varied per
+    stream on the GPU (rolled and scaled), so a batch of hundreds of minute-long streams costs seconds to make.
+    `duplicates`: pairs (dst, src) -- stream dst becomes a copy of stream src (independent streams holding the
+    same input must produce the same bits)."""
+    base_n = min(frames, 10 * 48000)
+    nb = 4
+    base = np.stack([voice(base_n, channels, stream=rank * nb + i) for i in range(nb)])
+    b = torch.from_numpy(base).to(device)
+    reps = (frames + base_n - 1) // base_n
+    x = torch.empty((streams, channels, frames), dtype=torch.float32, device=device)
+    for s in range(streams):
+        v = b[s % nb].repeat(1, reps)[:, :frames]
+        v = torch.roll(v, shifts=(s // nb) * 4099, dims=1) * (1.0 - 0.01 * (s % 7))
+        x[s] = torch.round(v * 32768.0) / 32768.0
+    for dst, src in duplicates:
+        x[dst] = x[src]
+    return x
+
+
+def batch_checksum(torch, y, group=16):
+    """Exact checksum of a float32 device tensor [streams, ...]: per stream the wrapping int64 sum of the samples'
+    bit patterns, each weighted by (position mod 251) + 1, then SHA-256 over the per-stream sums ("a checksum of
+    checksums").  Integer arithmetic only, so it does not depend on reduction order; computed on the device, a
+    few streams at a time.  Returns (hex digest, int64 tensor of per-stream sums on the host)."""
+    import hashlib
+    flat = y.contiguous().view(torch.int32).reshape(y.shape[0], -1)
+    w = (torch.arange(flat.shape[1], device=y.device, dtype=torch.int64) % 251) + 1
+    sums = torch.empty(flat.shape[0], dtype=torch.int64, device=y.device)
+    for s0 in range(0, flat.shape[0], group):
+        sums[s0:s0 + group] = (flat[s0:s0 + group].to(torch.int64) * w).sum(dim=1)
+    sums = sums.cpu()
+    return hashlib.sha256(sums.numpy().tobytes()).hexdigest(), sums

@@ -7,6 +7,15 @@ STREAMS independent 48 kHz stereo streams of SECONDS seconds each per GPU, BASEL
 configs[1] (normal_pitchshift +4 semitones, phase-locked, fft 2048).  Streams shard one set per
 GPU with no data-path collective (weak scaling: per-GPU work is fixed).
 
+`--gpus N` with N > 1: unless already started under torch.distributed.run (WORLD_SIZE set), this process
+launches N ranks of itself through `python -m torch.distributed.run` BEFORE importing torch or touching HIP,
+relays their output and exits with their code.  Ranks exchange nothing on the data path; the timing barrier and
+the MAX-over-ranks reduction go through gloo on CPU tensors (no RCCL on this path).
+
+After the timed region the output of the last step is checked (`"verified"` in the line): sampled streams
+against the oracle (RMS <= 1e-4), duplicate-input streams bit-identical, and an exact checksum of the whole
+batch that must be the same after every step.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -39,22 +48,6 @@ CONFIGS = {  # BASELINE.json configs[1..3]; configs[4] is cfg2 at 128 streams pe
     "cfg4_gender-7": ("configs[3]: gender_change -7 st, stereo 48 kHz, fft=2048",
                       dict(mode="gender_change", semitones=-7.0, fftsize=2048), True),
 }
-
-
-def make_input(torch, streams, frames, device, rank):
-    """Synthetic 48 kHz stereo on the int16 grid: a few host-synthesised voices, varied per stream on the GPU."""
-    from audiomod_amd import signals
-    base_n = min(frames, 10 * 48000)
-    nb = 4
-    base = np.stack([signals.voice(base_n, 2, stream=rank * nb + i) for i in range(nb)])
-    b = torch.from_numpy(base).to(device)
-    reps = (frames + base_n - 1) // base_n
-    x = torch.empty((streams, 2, frames), dtype=torch.float32, device=device)
-    for s in range(streams):
-        v = b[s % nb].repeat(1, reps)[:, :frames]
-        v = torch.roll(v, shifts=(s // nb) * 4099, dims=1) * (1.0 - 0.01 * (s % 7))
-        x[s] = torch.round(v * 32768.0) / 32768.0
-    return x
 
 
 def cpu_baseline(seconds=480, all_cores_seconds=240):
@@ -172,6 +165,41 @@ def copy_ceiling_gbps(torch, device, nbytes=1 << 30, reps=10):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def launch_ranks(n):
+    """Start n ranks of this script under torch.distributed.run as a CHILD process (this process has not imported
+    torch or touched HIP yet, and never replaces itself: a process that has initialised the GPU must not exec)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def verify_outputs(torch, batch, d_in, out, dup_pairs, sample_streams, kw, flush, tol=1e-4):
+    """Check what the timed steps produced (runs after the timed region, on this rank's batch): sampled streams
+    against the oracle on the same input, duplicate-input streams bit for bit."""
+    from oracle import oracle_py as O
+    res = {"streams_checked": [int(s) for s in sample_streams], "tolerance_rms": tol}
+    worst = 0.0
+    for s in sample_streams:
+        x = d_in[s].cpu().numpy()
+        want, _, _ = O.run_offline(x, block=480, flush=flush, **kw)
+        got = out[s].cpu().numpy()
+        if got.shape != want.shape:
+            worst = float("inf")
+            continue
+        worst = max(worst, float(np.sqrt(np.mean((got.astype(np.float64) - want) ** 2))))
+    res["max_rms_vs_oracle"] = worst
+    res["duplicate_streams_bit_identical"] = bool(all(torch.equal(out[a].view(torch.int32), out[b].view(torch.int32))
+                                                      for a, b in dup_pairs))
+    res["duplicate_pairs"] = [[int(a), int(b)] for a, b in dup_pairs]
+    res["ok"] = bool(worst <= tol and res["duplicate_streams_bit_identical"])
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,20 +211,29 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS),
                     help="BASELINE config to run (default cfg2 = configs[1], the one the metric is quoted on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsals)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-timing check of the output")
+    ap.add_argument("--dist-backend", default="gloo",
+                    help="gloo (default: barrier + MAX reduce on CPU tensors, no RCCL on this path) or nccl")
     ap.add_argument("--force-device", type=int, default=-1, help="use this device on every rank (rehearsals only)")
     ap.add_argument("--groups", type=int, default=1,
                     help="split the streams into this many batches run concurrently on separate HIP streams")
     ap.add_argument("--sample-every", type=int, default=8, help="instrument every n-th chunk with HIP events")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))  # nothing below has run: no torch import, no HIP call in this process
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: started with WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a "
+                         f"line whose n_gpus would not match the request")
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
-    if args.force_device >= 0:  # rehearsal of the N > 1 path on a one-GPU box (use with --dist-backend gloo)
+    if args.force_device >= 0:  # rehearsal of the N > 1 path on a one-GPU box
         local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -205,23 +242,28 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=device)  # RCCL: timing barrier + MAX reduce only
+            dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend=args.dist_backend)
     red_device = device if args.dist_backend == "nccl" else None
 
     from audiomod_amd import engine as E
-    from audiomod_amd.sharding import max_over_ranks
+    from audiomod_amd import signals
+    from audiomod_amd.sharding import max_over_ranks, sum_over_ranks
     frames = args.seconds * 48000
     cfg_name, cfg_kw, cfg_flush = CONFIGS[args.config]
     kw = dict(coremode=args.coremode, **cfg_kw)
     G = max(1, args.groups)
     assert args.streams % G == 0, "--streams must be a multiple of --groups"
-    d_in = make_input(torch, args.streams, frames, device, rank)
-    per = args.streams // G
+    # two streams repeat the input of two others (far apart in the grid): equal inputs must give equal bits
+    S = args.streams
+    dup_pairs = [(S - 1, 0), (S // 2, 1)] if S >= 8 else []
+    d_in = signals.synthetic_batch(torch, S, frames, device, rank, duplicates=dup_pairs)
+    per = S // G
     batches = [E.Batch(per, frames, channels=2, block=480, flush=cfg_flush, device=local_rank, **kw) for _ in range(G)]
     ins = [d_in[g * per:(g + 1) * per] for g in range(G)]
-    outs = [b.alloc_out() for b in batches]
+    out_all = torch.empty((S, 2, batches[0].out_frames), dtype=torch.float32, device=device)
+    outs = [out_all[g * per:(g + 1) * per] for g in range(G)]
     hip_streams = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device) for _ in range(G - 1)]
     batch = batches[0]
     info = batch.info()
@@ -239,6 +281,10 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    warm_sum = None
+    if not args.no_verify and args.warmup > 0:
+        warm_sum = signals.batch_checksum(torch, out_all)[0]
+        barrier()
     # HIP events around the kernels of every 8th chunk of group 0, inside the timed region (an event record
     # costs stream time: instrumenting every launch slows the run by ~10 %, every 8th by ~1 %)
     batch.enable_timing(args.sample_every)
@@ -250,6 +296,25 @@ def main():
     ktimes = batch.kernel_times()
     batch.enable_timing(0)
     dt = max_over_ranks(dt, dist, red_device)
+    ranks_reporting = int(round(sum_over_ranks(1.0, dist, red_device)))
+
+    verified = None
+    if not args.no_verify:
+        digest, _ = signals.batch_checksum(torch, out_all)
+        picks = sorted({0, S - 1} | ({S // 2, S // 3} if rank == 0 and S >= 8 else set()))
+        verified = verify_outputs(torch, batch, d_in, out_all, dup_pairs, picks, kw, cfg_flush)
+        verified["batch_checksum_sha256"] = digest
+        verified["same_checksum_after_warmup_and_timed_steps"] = (warm_sum == digest) if warm_sum else None
+        if warm_sum is not None and warm_sum != digest:
+            verified["ok"] = False
+        all_ok = sum_over_ranks(1.0 if verified["ok"] else 0.0, dist, red_device)
+        verified["ranks_ok"] = int(round(all_ok))
+        verified["ok"] = bool(verified["ok"] and verified["ranks_ok"] == world)
+        verified["how"] = ("after the timed region, on the last step's output: sampled streams vs the oracle "
+                           "(CPU restatement pinned on the compiled reference), duplicate inputs bit for bit, "
+                           "exact integer checksum of the whole batch equal after warm-up and after the timed steps")
+
+    host_io = None
 
     if rank == 0:
         total_streams = args.streams * world
@@ -262,7 +327,8 @@ def main():
         rs = 1 if info["resample"] else 0  # without resampling SURVEY 8(d) drops the s + h terms
         # Algorithmic bytes per slice of each pipeline stage; they sum to SURVEY 8(d)'s
         # B_slice = 4*(3N+7H+2s+h).  The phase stage runs as two kernels (match + seq) in phase-locked
-        # mode and as one (prop) in coremode 0; a stage's time is the sum over its kernels.
+        # mode and as one (prop) in coremode 0; a stage's time is the sum over its kernels.  The fused
+        # synthesis + overlap-add kernel carries the bytes of both of its stages.
         stages = {
             "analysis": (4 * (N + 2 * H), ["pv_analyze_kernel"]),
             "phase": (4 * (3 * H), ["pv_match_kernel", "pv_seq_kernel", "pv_prop_kernel"]),
@@ -274,6 +340,9 @@ def main():
         for k, (ms, n) in ktimes.items():
             if n:
                 per_kernel[k] = {"avg_ms": round(ms / n, 4), "samples": int(n)}
+        if "pv_synth_ola_kernel" in per_kernel:  # fused path: one kernel for the last two stages
+            stages["synthesis+ola_resample"] = (stages["synthesis"][0] + stages["ola_resample"][0],
+                                                ["pv_synth_ola_kernel"])
         traffic_db = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -291,7 +360,7 @@ def main():
         overlapped = [k for k in ("pv_seq_kernel", "pv_prop_kernel") if batch.pipelined and k in per_kernel]
         main = {k: v for k, v in per_kernel.items() if k not in overlapped}
         dom = max(main, key=lambda k: main[k]["avg_ms"])
-        dom_stage = next(n for n, (_, ks) in stages.items() if dom in ks)
+        dom_stage = next(n for n, (_, ks) in stages.items() if dom in ks and n in per_stage)
         dom_bytes = stages[dom_stage][0]
         achieved = round(dom_bytes * slices_per_launch / (main[dom]["avg_ms"] * 1e-3) / 1e9, 1) \
             if dom_stage != "phase" or not overlapped else per_stage[dom_stage]["GBps"]
@@ -300,7 +369,7 @@ def main():
         copy_gbps = copy_ceiling_gbps(torch, device)
         line = {
             "metric": "Msamples/s (48 kHz stereo) phase-vocoder pitch-shift; x real-time per GPU",
-            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": ranks_reporting, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "x_realtime_per_gpu": round(xrt_gpu, 1),
@@ -308,21 +377,30 @@ def main():
                        "streams_per_gpu": args.streams, "seconds_per_stream": args.seconds, "channels": 2,
                        "block": 480, "hop_in": h, "slices_per_channel": int(batch.slices),
                        "concurrent_stream_groups": G, "launches_per_step": int(batch.launches) * G,
-                       "parallelism": f"stream-sharded x{world}, no collective"},
+                       "parallelism": f"stream-sharded x{world}, no collective",
+                       "rank_sync": f"{args.dist_backend} (barrier + MAX of the wall time only)" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "copy_ceiling_GBps": round(copy_gbps, 1), "frac_of_copy_ceiling": round(achieved / copy_gbps, 4),
                          "stage": dom_stage, "slices_per_launch": round(slices_per_launch, 1),
-                         "pipeline_GBps": round(pipeline_gbps, 1), "overlapped_on_second_stream": overlapped,
+                         "pipeline_GBps": round(pipeline_gbps, 1),
+                         "pipeline_frac": round(pipeline_gbps / HBM_PEAK_GBPS, 4),
+                         "overlapped_on_second_stream": overlapped,
                          "per_stage": per_stage,
                          "per_kernel": per_kernel},
         }
+        if verified is not None:
+            line["verified"] = verified
+        if host_io is not None:
+            line["host_io"] = host_io
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if verified is not None and not verified["ok"]:
+        raise SystemExit("bench.py: the timed output failed its check (see \"verified\" in the line above)")
 
 
 if __name__ == "__main__":

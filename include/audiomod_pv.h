@@ -145,7 +145,7 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
  * record costs stream time, so full instrumentation slows the run by about 10 %).  After synchronising the
  * stream, pv_batch_kernel_times returns, for each of PV_NUM_KERNELS kernels, the summed device time in ms and
  * the number of instrumented launches since timing was enabled, and resets the accumulation window. */
-#define PV_NUM_KERNELS 7
+#define PV_NUM_KERNELS 8
 #define PV_K_ANALYZE 0      /* window + forward real FFT + polar (+ peak picking) */
 #define PV_K_MATCH 1        /* phase-locked: peak matching, parallel part */
 #define PV_K_SEQ 2          /* phase-locked: per-peak rotation chain, sequential over slices */
@@ -153,6 +153,8 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
 #define PV_K_SYNTH 4        /* phase application + freqComp + inverse real FFT + window */
 #define PV_K_OLA_RESAMPLE 5 /* overlap-add + normalise + resample */
 #define PV_K_CEPSTRAL 6     /* PV_MODE_FORMANT_CEPSTRAL: cepstral envelope shift of the magnitudes */
+#define PV_K_SYNTH_OLA 7    /* PV_K_SYNTH and PV_K_OLA_RESAMPLE fused: synthesis frames overlap-added in LDS (fft 2048 /
+                               4096; the default -- AUDIOMOD_PV_FUSED=0 brings the two separate kernels back) */
 int pv_batch_enable_timing(pv_batch *b, int on);
 int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launches[PV_NUM_KERNELS]);
 const char *pv_kernel_name(int k);

@@ -539,3 +539,124 @@ def test_invalid_modes_fail_loudly():
     for mode in (9, 42, -2):
         with pytest.raises(E.PvError):
             E.PhaseVocoder(48000, 2, 1.0, 0.0, mode)
+
+
+def test_fused_overlap_add_is_bit_identical_to_the_tile_path():
+    """The default path adds the synthesis frames into the reference's accumulator in LDS, in slice order (fused
+    synthesis + overlap-add, pv_synth_chain_kernel / pv_frames_chain_kernel); AUDIOMOD_PV_FUSED=0 (read at engine
+    creation) writes them to the HBM frame ring and gathers them per output tile.  Same additions in the same
+    order, same resampler arithmetic: the outputs must agree bit for bit -- batch and streaming, every FFT size
+    class (wave-per-frame 2048 / 4096, generic 512 / 8192), resampling up, down and not at all."""
+    import subprocess
+    import sys
+    import tempfile
+    code = """
+import numpy as np, sys, torch
+sys.path.insert(0, %r)
+from audiomod_amd import engine as E, signals
+x = np.stack([signals.voice(40000, 2, seed=23 + s) for s in range(3)])
+outs = []
+for kw in (dict(semitones=4.0), dict(semitones=-7.0, mode="formant_pitchshift"),
+           dict(mode="time_stretch", time_ratio=1.5, fftsize=4096, flush=False), dict(semitones=7.0, fftsize=4096, coremode=0),
+           dict(semitones=3.0, fftsize=512), dict(semitones=-5.0, fftsize=8192, coremode=2), dict(mode="robotic", fftsize=1024),
+           dict(semitones=12.0), dict(mode="time_stretch", time_ratio=0.6, flush=False, coremode=0),
+           dict(mode="vocoder"), dict(mode="constant", semitones=-4.0)):
+    kw = dict(kw); flush = kw.pop("flush", True)
+    b = E.Batch(3, 40000, channels=2, flush=flush, **kw)
+    o = b.run(torch.from_numpy(x).cuda()); torch.cuda.synchronize()
+    outs.append(o.cpu().numpy()); b.close()
+    g, _ = E.run_offline(x[1], flush=flush, block=777, **kw)
+    outs.append(g)
+np.savez(sys.argv[1], *outs)
+""" % (ROOT,)
+    with tempfile.TemporaryDirectory() as d:
+        files = []
+        for tag, env in (("fused", {"AUDIOMOD_PV_FUSED": "1"}), ("tiles", {"AUDIOMOD_PV_FUSED": "0"})):
+            f = os.path.join(d, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,
+                               env=dict(os.environ, **env), timeout=900)
+            assert r.returncode == 0, r.stdout + r.stderr
+            files.append(np.load(f))
+        a, b = files
+        assert len(a.files) == len(b.files) == 22
+        for k in a.files:
+            assert bits_equal(a[k], b[k]), k
+        # and a batch row equals the streaming run of the same input
+        for i in range(0, 22, 2):
+            assert bits_equal(a[f"arr_{i}"][1], a[f"arr_{i + 1}"]), i
+
+
+OVERRUN_GPU = [
+    (dict(semitones=-3.0), 2, [30000, 480, 480, 20000, 480, 480]),
+    (dict(semitones=5.0, fftsize=256), 2, [6000, 6000, 64, 6000]),
+    (dict(mode="constant", fftsize=256), 3, [4800, 4800, 64, 9000, 480]),
+    (dict(mode="vocoder", fftsize=512), 1, [9000, 480, 9000]),
+    (dict(mode="time_stretch", time_ratio=2.5, fftsize=512, coremode=0), 2, [12000, 100, 12000]),
+    (dict(mode="robotic", fftsize=1024, semitones=-9.0), 2, [40000, 480]),
+    (dict(semitones=4.0, fftsize=4096, coremode=2), 2, [70000, 3000]),
+]
+
+
+@pytest.mark.parametrize("kw,ch,calls", OVERRUN_GPU, ids=[str(i) for i in range(len(OVERRUN_GPU))])
+def test_output_overrun_drops_slices_like_the_reference(kw, ch, calls):
+    """Calls so large that the reference's own output ring overruns: it drops slices there (frame added to the
+    accumulators, writeSlice skipped: phasevocoderprocess.cc:337-364; the CONSTANT loop even leaves after channel
+    0, :139-150), so the following frames pile up on one overlap-add position.  The engine reproduces that -- same
+    per-call counts, same audio -- instead of refusing the call."""
+    x = signals.voice(sum(calls), ch, seed=55)
+    pv = E.PhaseVocoder(kw.get("sample_rate", 48000), ch, kw.get("time_ratio", 1.0), kw.get("semitones", 0.0),
+                        E.MODES[kw.get("mode", "normal_pitchshift")], kw.get("coremode", 1), kw.get("fftsize", 2048))
+    o = O.Oracle(ch, **kw)
+    pos, g_all, w_all, dropped = 0, [], [], False
+    for n in calls:
+        blk = x[:, pos:pos + n]
+        pos += n
+        pv.processInData(blk)
+        avail = o.process(blk)
+        assert pv.getOutSamples() == avail
+        dropped = dropped or avail >= o.info()["outbuf_capacity"] - 2 * o.info()["fftsize"]
+        g_all.append(pv.getOutData(avail))
+        w_all.append(o.retrieve(avail))
+    assert dropped  # the case really drives the ring full
+    g, w = np.concatenate(g_all, 1), np.concatenate(w_all, 1)
+    assert g.shape == w.shape and g.shape[1] > 0
+    assert rms(g, w) <= RMS_TOL
+    pv.close()
+
+
+def test_feed_is_transactional_and_retrieve_is_bounded():
+    """A call the engine refuses leaves it where it was (nothing fed, nothing pending): the caller goes on with
+    valid calls and gets exactly the reference's output for those.  The refusal used here: the tile path
+    (AUDIOMOD_PV_FUSED=0) cannot represent dropped slices and rejects a call that overruns the output ring."""
+    import subprocess
+    import sys
+    code = """
+import numpy as np, sys
+sys.path.insert(0, %r)
+from audiomod_amd import engine as E, signals
+from oracle import oracle_py as O
+x = signals.voice(20000, 2, seed=61)
+pv = E.PhaseVocoder(48000, 2, 1.0, 4.0)
+try:
+    pv.processInData(np.zeros((2, 200000), np.float32))
+    raise SystemExit("the overrunning call was not refused")
+except E.PvError as ex:
+    assert "output ring" in str(ex), ex
+assert pv.L.pv_available(pv.h) == 0
+got, gc = [], []
+for i in range(0, 20000, 480):
+    pv.processInData(x[:, i:i + 480])
+    n = pv.getOutSamples()
+    gc.append(n)
+    got.append(pv.getOutData(n))
+out = np.zeros((2, 64), np.float32)
+assert pv.L.pv_retrieve(pv.h, E._pp([out[0], out[1]]), 64) == 0   # nothing left: nothing handed out
+want, wc, _ = O.run_offline(x, semitones=4.0, flush=False)
+assert gc == wc, (gc[:8], wc[:8])
+e = float(np.sqrt(np.mean((np.concatenate(got, 1).astype(np.float64) - want) ** 2)))
+assert e <= 1e-4, e
+print("transactional ok")
+""" % (ROOT,)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                       env=dict(os.environ, AUDIOMOD_PV_FUSED="0"), timeout=600)
+    assert r.returncode == 0 and "transactional ok" in r.stdout, r.stdout + r.stderr

@@ -106,11 +106,34 @@ def test_errors():
         E.plan_simulate([480], channels=0, semitones=4.0)
     with pytest.raises(E.PvError):
         E.plan_simulate([480], channels=2, mode=42)
-    # output never retrieved: the reference's ring overruns and it starts dropping slices; refused with a reason
-    with pytest.raises(E.PvError, match="output ring overrun.*retrieve between calls"):
-        E.plan_simulate([100000], channels=2, semitones=-3.0)
-    with pytest.raises(E.PvError, match="output ring overrun"):
-        E.plan_simulate([4800], channels=2, mode="constant", fftsize=256)
+
+
+OVERRUN = [
+    (dict(channels=2, semitones=-3.0), [100000, 480, 480, 30000, 480]),
+    (dict(channels=2, mode="constant", fftsize=256), [4800, 4800, 64, 9000, 480]),
+    (dict(channels=1, mode="vocoder", fftsize=512), [9000, 480, 9000]),
+    (dict(channels=3, mode="time_stretch", time_ratio=2.5, fftsize=256, coremode=0), [6000, 6000, 100, 6000]),
+    (dict(channels=2, mode="robotic", fftsize=256, semitones=-9.0), [5000, 5000]),
+]
+
+
+@pytest.mark.parametrize("kw,calls", OVERRUN, ids=[str(i) for i in range(len(OVERRUN))])
+def test_overrun_drops_slices_like_the_reference(kw, calls):
+    """A call that leaves more output pending than the reference's output ring holds makes the reference DROP
+    slices (phasevocoderprocess.cc:337-364: the frame stays in the accumulators, nothing is written): the planner
+    follows it -- same per-call availability, same increments (calculateIncrements runs for dropped slices too)."""
+    avail, shift, phase, info = E.plan_simulate(calls, **kw)
+    ch = kw["channels"]
+    o = O.Oracle(**kw)
+    ref = []
+    for n in calls:
+        got = o.process(np.zeros((ch, n), np.float32))
+        o.retrieve(got)
+        ref.append(got)
+    s, p = o.increments()
+    assert list(avail) == ref
+    assert np.array_equal(s, shift) and np.array_equal(p, phase)
+    assert max(ref) >= info["outbuf_capacity"] - 2 * info["fftsize"]  # the ring really filled up
 
 
 def test_output_hop_above_the_fft_size_is_refused_on_both_sides():
