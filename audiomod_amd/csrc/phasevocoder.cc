@@ -4,6 +4,7 @@
 // available.  The reference's stdout chatter (:76-83,130,147) is not reproduced.
 #include "dafx/phasevocoder.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
@@ -51,12 +52,20 @@ phasevocoder::~phasevocoder() {
     engine_ = nullptr;
 }
 
+// The reference's entry points neither return a status nor throw: a shortfall shows as fewer samples /
+// outputReady() == false plus a line on stderr (phasevocoder.cc:146-151, circularqueue.h:337-341).  Same here: a
+// call the engine refuses leaves it untouched (pv_feed is transactional), the caller sees no new samples.
+static void report(const char *where, int st) {
+    std::fprintf(stderr, "audiomod::phasevocoder (MI355X engine): %s: %s: %s\n", where, pv_strerror(st), pv_last_error());
+}
+
 void phasevocoder::processInData(float *const *inData, int num_in_samples) {
     int numres = 0;
     if (served_by_process_normal(mode_)) {
         const int st = pv_feed(engine_, inData, num_in_samples);
-        if (st != PV_OK) throw std::runtime_error(std::string("pv_feed: ") + pv_strerror(st) + ": " + pv_last_error());
+        if (st != PV_OK) report("processInData", st);
         numres = pv_available(engine_);
+        if (numres < 0) numres = 0;
     }
     num_res_ = numres;
 }
@@ -72,7 +81,11 @@ void phasevocoder::processBlock(float *const *bufferData, int num_samples) {
     int ret = 0;
     if (served_by_process_normal(mode_) && mode_ != NORMAL_STRETCH) {
         const int st = pv_feed(engine_, bufferData, num_samples);
-        if (st != PV_OK) throw std::runtime_error(std::string("pv_feed: ") + pv_strerror(st) + ": " + pv_last_error());
+        if (st != PV_OK) {
+            report("processBlock", st);
+            outready_ = false; // the block stays as the caller passed it
+            return;
+        }
         const int numres = pv_available(engine_);
         num_res_ = numres;
         if (numres >= num_samples) {

@@ -108,17 +108,16 @@ template <typename T> struct PinBuf {
 // ------------------------------------------------------------------------------------------
 struct ChainBuilder {
     const Derived &d;
-    int AR, SR;
-    int64_t E = 0;       // outputs handed to waves so far
-    bool started = false;
+    int AR, smask;
     struct Live {
         int64_t P;
         int32_t flags;
     };
     std::deque<Live> live; // frames that may still cover samples not yet finalised, oldest first
     bool any_upper_skip = false;
+    int64_t launch_k0 = 0; // first output of the current launch (begin_launch)
 
-    ChainBuilder(const Derived &dd, int ar, int sr) : d(dd), AR(ar), SR(sr) {}
+    ChainBuilder(const Derived &dd, int ar, int mask) : d(dd), AR(ar), smask(mask) {}
 
     static int32_t pmod(int64_t v, int m) {
         int64_t r = v % m;
@@ -135,63 +134,40 @@ struct ChainBuilder {
         }
         return acc;
     }
-    // One slice.  last_of_launch: its wave also emits the outputs that do not fill a block of 64.
     // out_limit: outputs at or beyond it are not written (the CLI truncates to the input length).
-    void add(const SliceRec &r, bool last_of_launch, int64_t out_limit, std::vector<ChainSlice> &cs,
-             std::vector<float> &wden, std::vector<float> &wden_hi, std::vector<uint2> &otab) {
+    void add(const SliceRec &r, int64_t out_limit, std::vector<ChainSlice> &cs, std::vector<float> &wden,
+             std::vector<float> &wden_hi) {
         ChainSlice c{};
         c.acc_pos = pmod(r.P, AR);
-        c.str_pos = pmod(r.P, SR);
+        c.str_pos = (int32_t)(r.P & (int64_t)smask);
         c.adv = r.adv;
         c.flags = r.flags;
         if (r.flags & kSliceUpperChannelsSkip) any_upper_skip = true;
         live.push_back(Live{r.P, r.flags});
+        // denominators by ring quads: entry 0 belongs to sample P - (P mod 4); entries outside [P, P + adv) are
+        // never used (1.0); every slice starts on a 16-byte boundary
+        while (wden.size() & 3) wden.push_back(1.f), wden_hi.push_back(1.f);
         c.wden_off = (int32_t)wden.size();
-        for (int i = 0; i < r.adv; ++i) {
-            wden.push_back(denominator(r.P + i, false));
-            wden_hi.push_back(any_upper_skip ? denominator(r.P + i, true) : wden.back());
+        const int lead = c.acc_pos & 3;
+        for (int i = -lead; i < ((r.adv + lead + 3) & ~3) - lead; ++i) {
+            const bool in = i >= 0 && i < r.adv;
+            wden.push_back(in ? denominator(r.P + i, false) : 1.f);
+            wden_hi.push_back(in && any_upper_skip ? denominator(r.P + i, true) : wden.back());
         }
         const int64_t Pn = r.P + r.adv;
         while (!live.empty() && live.front().P + d.N <= Pn) live.pop_front();
-        // outputs: every k below K0 + cnt is computable now; whole blocks of 64 go to this wave, the remainder to
-        // the next slice's (a wave's lanes then always work in full rows), except at the end of a launch
-        const int64_t Kn = r.K0 + r.cnt;
-        int64_t Eto = d.resample ? (last_of_launch ? Kn : (Kn / 64) * 64) : Kn;
-        if (Eto < E) Eto = E;
-        int64_t lo = E, hi = Eto;
-        if (!d.resample) lo = r.K0, hi = Kn; // outputs are the finalised samples themselves
-        if (hi > out_limit) hi = out_limit;
-        if (lo > hi) lo = hi;
-        c.k_off = (int32_t)(lo - launch_k0);
-        c.kcnt = (int32_t)(hi - lo);
-        c.otab_off = (int32_t)otab.size();
-        if (d.resample) {
-            for (int64_t k = lo; k < hi; ++k) {
-                // last_sample = filt_len/2 + floor(k*num/den), samp_frac_num = (k*num) mod den: closed form of
-                // resample.c:548-554 from skip_zeros (:1225); sub-sample offset and interpolation fraction as
-                // resampler_basic_interpolate_single computes them (:494-500)
-                const unsigned __int128 tot = (unsigned __int128)k * d.res_num;
-                const int64_t pos = (int64_t)(d.filt_len / 2) + (int64_t)(tot / d.res_den);
-                const uint32_t frac_num = (uint32_t)(tot % d.res_den);
-                uint32_t sub, fbits = 0;
-                if (d.interp) {
-                    const uint32_t ov = (uint32_t)d.oversample;
-                    sub = frac_num * ov / d.res_den;
-                    const float frac = ((float)((frac_num * ov) % d.res_den)) / d.res_den;
-                    memcpy(&fbits, &frac, 4);
-                } else {
-                    sub = frac_num;
-                }
-                otab.push_back(make_uint2((uint32_t)pmod(pos - d.filt_len + 1, SR) | (sub << 24), fbits));
-            }
+        if (!d.resample) { // the finalised samples are the outputs
+            int64_t lo = r.K0, hi = r.K0 + r.cnt;
+            if (hi > out_limit) hi = out_limit;
+            if (lo > hi) lo = hi;
+            c.k_off = (int32_t)(lo - launch_k0);
+            c.kcnt = (int32_t)(hi - lo);
         }
-        E = Eto;
         cs.push_back(c);
     }
-    int64_t launch_k0 = 0; // first output of the current launch (set by begin_launch)
-    // the first output the launch's waves may emit, relative to which k_off counts
+    // the first output of the launch, relative to which k_off counts
     int64_t begin_launch(const SliceRec &first) {
-        launch_k0 = d.resample ? E : first.K0;
+        launch_k0 = first.K0;
         return launch_k0;
     }
 };
@@ -200,8 +176,11 @@ struct ChainBuilder {
 struct ChainLaunch {
     const ChainSlice *slices; // [Tn] device
     const float *wden, *wden_hi;
-    const uint2 *otab;
     float *out;               // the row-0 address of the launch's first output
+    // resampling configurations: the second kernel's tiles for the outputs this launch completes
+    const ResTile *res_tiles;
+    const uint2 *res_otab;
+    int res_ntiles;
 };
 
 struct Core {
@@ -229,9 +208,11 @@ struct Core {
     // their images are carried here between launches.  On by default (AUDIOMOD_PV_FUSED=0 selects the frame ring +
     // tile kernel instead, which cannot represent dropped slices).
     bool use_chain = false;
-    int chain_AR = 0, chain_SR = 0, chain_mirror = 0, chain_waves = 0;
+    int chain_AR = 0, chain_smask = 0, chain_waves = 0;
     int chain_max_adv = 0; // set before init(): the largest overlap-add advance the planner can emit
-    DevBuf<float> st_acc, st_str;
+    DevBuf<float> st_acc, stream; // accumulator-ring images; normalised overlap-add stream rings (resampling only)
+    // resample tiles (outputs [ka, kb)) of the fused path
+    void build_res_tiles(int64_t ka, int64_t kb, std::vector<ResTile> &tiles, std::vector<uint2> &otab) const;
     static bool chain_wanted() {
         const char *e = getenv("AUDIOMOD_PV_FUSED");
         if (e && atoi(e) == 0) return false;
@@ -330,30 +311,31 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
             chain_max_adv = (int)(m < d.N ? m + 1 : d.N);
         }
         chain_AR = d.N + 4;
-        chain_mirror = d.resample ? ((d.filt_len + 3) & ~3) : 4;
-        const int span64 = d.resample ? (int)((64ull * d.res_num + d.res_den - 1) / d.res_den) + 2 : 0;
-        const int wmax = d.fft.nc == 2048 ? 8 : 14;
+        // (beside the rotation chain's kernel -- the pipelined batch path -- twelve: its six-wave workgroups then
+        // find a CU's fourth wave slot and 8 KB of LDS free and run at their stand-alone speed; with fourteen or
+        // sixteen they wait for a fused workgroup to finish and the overlap is gone: 54.1 vs 58.6 ms per step)
+        int wmax = d.fft.nc == 2048 ? 8 : (pipelined_planes ? 12 : 16);
+        if (const char *e = getenv("AUDIOMOD_PV_CHAIN_WAVES")) { // tuning knob: upper bound of waves per workgroup
+            const int v = atoi(e);
+            if (v >= 1 && v < wmax) wmax = v;
+        }
         ChainArgs probe{};
         probe.AR = chain_AR;
-        probe.mirror = chain_mirror;
-        probe.tab_bytes = !d.resample ? 0
-                          : d.interp  ? d.oversample * (d.filt_len + 1) * 16
-                                      : (int)((d.sinc.size() * sizeof(float) + 15) & ~(size_t)15);
         chain_waves = 0;
         for (int w = wmax; w >= 1; --w) {
-            const int sr = (w * chain_max_adv + (d.resample ? d.filt_len : 0) + span64 + 8 + 3) & ~3;
-            probe.SR = sr;
             probe.waves = w;
             if (chain_lds_bytes(probe, wave_fft() ? d.fft.nc : 0) <= 160 * 1024 - 512) {
                 chain_waves = w;
-                chain_SR = sr;
                 break;
             }
         }
         if (chain_waves == 0) {
-            g_last_error = "the overlap-add rings of this configuration do not fit the LDS";
+            g_last_error = "the overlap-add ring of this configuration does not fit the LDS";
             return PV_ERR_UNSUPPORTED;
         }
+        // the stream ring keeps what one launch finalises plus the history the next launch's first windows reach
+        // back into (one filter length), with room to spare
+        chain_smask = next_pow2_i(2 * chunk_slices * chain_max_adv + 4 * d.N + 1024) - 1;
     }
     Tc = chunk_slices;
     // slice-indexed planes keep the last slice of the previous launch (pv_kernels.h); the pipelined batch path
@@ -449,7 +431,8 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
         if ((st = frames.alloc((size_t)rows * FR * d.N)) != PV_OK) return st;
     if (use_chain) {
         if ((st = st_acc.alloc((size_t)rows * chain_AR)) != PV_OK) return st;
-        if ((st = st_str.alloc((size_t)rows * (chain_SR + chain_mirror))) != PV_OK) return st;
+        if (d.resample)
+            if ((st = stream.alloc((size_t)rows * ((size_t)chain_smask + 1))) != PV_OK) return st;
     }
     const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder; // modes without a phase recurrence
     if (d.vocoder) {
@@ -478,7 +461,6 @@ int Core::reset_state(hipStream_t st) {
     if (st_po.p) HIPC(hipMemsetAsync(st_po.p, 0, st_po.n * sizeof(float), st));
     if (st_kind.p) HIPC(hipMemsetAsync(st_kind.p, 0, st_kind.n * sizeof(int32_t), st));
     if (st_acc.p) HIPC(hipMemsetAsync(st_acc.p, 0, st_acc.n * sizeof(float), st));
-    if (st_str.p) HIPC(hipMemsetAsync(st_str.p, 0, st_str.n * sizeof(float), st));
     return PV_OK;
 }
 
@@ -591,6 +573,43 @@ int Core::build_tiles(const std::vector<SliceRec> &slices, int64_t t_base, int64
         }
     }
     return PV_OK;
+}
+
+void Core::build_res_tiles(int64_t ka, int64_t kb, std::vector<ResTile> &tiles, std::vector<uint2> &otab) const {
+    for (int64_t k0 = ka; k0 < kb; k0 += kTileOut) {
+        ResTile tl{};
+        tl.k0 = k0;
+        tl.kcnt = (int32_t)((kb - k0) < kTileOut ? (kb - k0) : kTileOut);
+        auto pos = [&](int64_t k) {
+            return (int64_t)(d.filt_len / 2) + (int64_t)(((unsigned __int128)k * d.res_num) / d.res_den);
+        };
+        tl.n_lo = pos(k0) - d.filt_len + 1;
+        tl.n_cnt = (int32_t)(pos(k0 + tl.kcnt - 1) - tl.n_lo + 1);
+        tiles.push_back(tl);
+        // where each output of the tile sits in the stream: last_sample = filt_len/2 + floor(k*num/den),
+        // samp_frac_num = (k*num) mod den (closed form of resample.c:548-554 from skip_zeros :1225), and from those
+        // the sub-sample offset and the interpolation fraction of resampler_basic_interpolate_single (:494-500)
+        for (int o = 0; o < kTileOut; ++o) {
+            if (o >= tl.kcnt) {
+                otab.push_back(make_uint2(0u, 0u));
+                continue;
+            }
+            const unsigned __int128 tot = (unsigned __int128)(k0 + o) * d.res_num;
+            const int64_t p = (int64_t)(d.filt_len / 2) + (int64_t)(tot / d.res_den);
+            const uint32_t frac_num = (uint32_t)(tot % d.res_den);
+            const uint32_t xoff = (uint32_t)(p - d.filt_len + 1 - tl.n_lo);
+            uint32_t sub, fbits = 0;
+            if (d.interp) {
+                const uint32_t ov = (uint32_t)d.oversample;
+                sub = frac_num * ov / d.res_den;
+                const float frac = ((float)((frac_num * ov) % d.res_den)) / d.res_den;
+                memcpy(&fbits, &frac, 4);
+            } else {
+                sub = frac_num;
+            }
+            otab.push_back(make_uint2(xoff | (sub << 16), fbits));
+        }
+    }
 }
 
 void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_pinc, const OlaTile *d_tiles,
@@ -781,32 +800,48 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ca.C = C;
         ca.Tn = Tn;
         ca.AR = chain_AR;
-        ca.SR = chain_SR;
-        ca.mirror = chain_mirror;
+        ca.smask = chain_smask;
         ca.waves = chain_waves;
+        {
+            static const int diag = [] {
+                const char *e = getenv("AUDIOMOD_PV_CHAIN_DIAG");
+                return e ? atoi(e) : 0;
+            }();
+            ca.diag = diag;
+        }
         ca.slices = chain->slices;
         ca.wden = chain->wden;
         ca.wden_hi = chain->wden_hi;
-        ca.otab = chain->otab;
         ca.st_acc = st_acc.p;
-        ca.st_str = st_str.p;
+        ca.stream = stream.p;
         ca.resample = d.resample ? 1 : 0;
-        ca.interp = d.interp ? 1 : 0;
-        ca.filt_len = d.filt_len;
-        ca.oversample = d.oversample;
-        ca.sinc = sinc.p;
-        ca.sinc_len = d.resample ? (int)d.sinc.size() : 0;
-        ca.tab4 = tab4.p;
-        ca.tab_bytes = !d.resample ? 0
-                       : d.interp  ? d.oversample * (d.filt_len + 1) * 16
-                                   : (int)((d.sinc.size() * sizeof(float) + 15) & ~(size_t)15);
         ca.out = chain->out;
         ca.out_stride_row = out_stride_row;
         ca.frames = frames.p;
         ca.FR = FR;
         ca.t0 = t0;
+        ResArgs ra{};
+        ra.rows = rows;
+        ra.ntiles = chain->res_ntiles;
+        ra.smask = chain_smask;
+        ra.stream = stream.p;
+        ra.tiles = chain->res_tiles;
+        ra.otab = chain->res_otab;
+        ra.interp = d.interp ? 1 : 0;
+        ra.filt_len = d.filt_len;
+        ra.oversample = d.oversample;
+        ra.sinc = sinc.p;
+        ra.sinc_len = d.resample ? (int)d.sinc.size() : 0;
+        ra.tab4 = tab4.p;
+        ra.lds_floats = ola_lds_floats;
+        ra.tab_bytes = !d.resample ? 0
+                       : d.interp  ? d.oversample * (d.filt_len + 1) * 16
+                                   : (int)((d.sinc.size() * sizeof(float) + 15) & ~(size_t)15);
+        ra.out = out;
+        ra.out_stride_row = out_stride_row;
+        ra.k_base = k_base;
         if (wave_fft()) {
-            // synthesis, overlap-add and resampling in one kernel: the frames stay in LDS
+            // synthesis and overlap-add in one kernel: the frames stay in LDS
             rec(2 * PV_K_SYNTH_OLA);
             launch_synth_chain(sa, ca, st);
             rec(2 * PV_K_SYNTH_OLA + 1);
@@ -816,6 +851,11 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
             rec(2 * PV_K_SYNTH + 1);
             rec(2 * PV_K_OLA_RESAMPLE);
             launch_frames_chain(ca, st);
+            if (!d.resample) rec(2 * PV_K_OLA_RESAMPLE + 1);
+        }
+        if (d.resample) {
+            if (wave_fft()) rec(2 * PV_K_OLA_RESAMPLE);
+            launch_resample(ra, st);
             rec(2 * PV_K_OLA_RESAMPLE + 1);
         }
         return;
@@ -902,11 +942,13 @@ struct pv_batch {
         int64_t t0;
         int Tn;
         int tile_begin, ntiles;
-        int64_t k0; // fused path: first output its waves emit
+        int64_t k0; // fused path: first output of the chunk
+        int res_begin, res_ntiles; // ... and its tiles of the resampling kernel
     };
     DevBuf<ChainSlice> d_cs; // fused path: one entry per slice of the plan
     DevBuf<float> d_wden, d_wden_hi;
-    DevBuf<uint2> d_otab;
+    DevBuf<ResTile> d_res_tiles;
+    DevBuf<uint2> d_res_otab;
     std::vector<Chunk> chunks;
     DevBuf<int32_t> d_pinc;
     DevBuf<int64_t> d_P;
@@ -1067,13 +1109,15 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
     std::vector<float> wacc;
     std::vector<ChainSlice> cs;
     std::vector<float> wden, wden_hi;
-    std::vector<uint2> otab;
-    ChainBuilder cb(c.d, c.chain_AR, c.chain_SR);
+    std::vector<ResTile> res_tiles;
+    std::vector<uint2> res_otab;
+    ChainBuilder cb(c.d, c.chain_AR, c.chain_smask);
     for (int64_t t0 = 0; t0 < T; t0 += Tc) {
         pv_batch::Chunk ch;
         ch.t0 = t0;
         ch.Tn = (int)((T - t0) < Tc ? (T - t0) : Tc);
         ch.k0 = 0;
+        ch.res_begin = ch.res_ntiles = 0;
         const int64_t t1 = t0 + ch.Tn;
         int64_t ka = sl[(size_t)t0].K0;
         int64_t kb = sl[(size_t)(t1 - 1)].K0 + sl[(size_t)(t1 - 1)].cnt;
@@ -1082,7 +1126,12 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
         ch.tile_begin = (int)tiles.size();
         if (c.use_chain) {
             ch.k0 = cb.begin_launch(sl[(size_t)t0]);
-            for (int64_t t = t0; t < t1; ++t) cb.add(sl[(size_t)t], t == t1 - 1, b->plan.out_frames, cs, wden, wden_hi, otab);
+            for (int64_t t = t0; t < t1; ++t) cb.add(sl[(size_t)t], b->plan.out_frames, cs, wden, wden_hi);
+            if (c.d.resample && kb > ka) {
+                ch.res_begin = (int)res_tiles.size();
+                c.build_res_tiles(ka, kb, res_tiles, res_otab);
+                ch.res_ntiles = (int)res_tiles.size() - ch.res_begin;
+            }
         } else if (kb > ka) {
             st = c.build_tiles(sl, 0, t1, ka, kb, 0, tiles, wacc);
             if (st != PV_OK) return st;
@@ -1096,15 +1145,15 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
     if ((st = b->d_wacc.upload(wacc)) != PV_OK) return st;
     if (c.use_chain) {
         // (one spare entry each: a slice that finalises or emits nothing still prefetches its first entry)
-        wden.push_back(1.f);
-        wden_hi.push_back(1.f);
-        otab.push_back(make_uint2(0u, 0u));
+        while (wden.size() & 3) wden.push_back(1.f), wden_hi.push_back(1.f);
+        for (int i = 0; i < 4; ++i) wden.push_back(1.f), wden_hi.push_back(1.f);
         if ((st = b->d_cs.upload(cs)) != PV_OK) return st;
         if ((st = b->d_wden.upload(wden)) != PV_OK) return st;
         if (cb.any_upper_skip) {
             if ((st = b->d_wden_hi.upload(wden_hi)) != PV_OK) return st;
         }
-        if ((st = b->d_otab.upload(otab)) != PV_OK) return st;
+        if ((st = b->d_res_tiles.upload(res_tiles)) != PV_OK) return st;
+        if ((st = b->d_res_otab.upload(res_otab)) != PV_OK) return st;
     }
     if (c.can_overlap_chain()) {
         // highest stream priority: the dispatcher must place the chain's few workgroups ahead of the thousands
@@ -1209,7 +1258,9 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
             cl.slices = b->d_cs.p + ch.t0;
             cl.wden = b->d_wden.p;
             cl.wden_hi = b->d_wden_hi.p ? b->d_wden_hi.p : b->d_wden.p;
-            cl.otab = b->d_otab.p;
+            cl.res_tiles = b->d_res_tiles.p + ch.res_begin;
+            cl.res_otab = b->d_res_otab.p + (size_t)ch.res_begin * kTileOut;
+            cl.res_ntiles = ch.res_ntiles;
             cl.out = d_out + ch.k0;
         }
         c.launch_chunk(ia, ch.t0, ch.Tn, b->d_pinc.p + ch.t0, b->d_tiles.p + ch.tile_begin, ch.ntiles, b->d_P.p,
@@ -1249,7 +1300,8 @@ int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launch
             if (k == PV_K_CEPSTRAL && !d.cepstral) continue;
             const bool fused = b->core.use_chain && b->core.wave_fft();
             if (k == PV_K_SYNTH_OLA && !fused) continue;
-            if ((k == PV_K_SYNTH || k == PV_K_OLA_RESAMPLE) && fused) continue;
+            if (k == PV_K_SYNTH && fused) continue;
+            if (k == PV_K_OLA_RESAMPLE && fused && !d.resample) continue; // the fused kernel emits the output itself
             if (k == PV_K_OLA_RESAMPLE && !b->core.use_chain) {
                 const int ci2 = b->ev_chunk[i / kEvPerChunk];
                 if (b->chunks[(size_t)ci2].ntiles == 0) continue;
@@ -1283,7 +1335,7 @@ int pv_create(const pv_config *cfg, int device, pv_engine **out) {
     if (st != PV_OK) return st;
     Core &c = e->core;
     e->planner.reset(new Planner(c.d));
-    if (c.use_chain) e->chain.reset(new ChainBuilder(c.d, c.chain_AR, c.chain_SR));
+    if (c.use_chain) e->chain.reset(new ChainBuilder(c.d, c.chain_AR, c.chain_smask));
     HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->ring = next_pow2_i(3 * c.d.N + kStreamChunk * c.d.hop + 16);
     if ((st = e->d_in.alloc((size_t)c.C * e->ring)) != PV_OK) return st;
@@ -1431,14 +1483,15 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         std::vector<OlaTile> tiles;
         std::vector<float> wacc, wden, wden_hi;
         std::vector<ChainSlice> cs;
-        std::vector<uint2> otab;
+        std::vector<ResTile> res_tiles;
+        std::vector<uint2> res_otab;
         if (c.use_chain) {
             e->chain->begin_launch(first);
             for (int64_t t = ta; t < tb; ++t)
-                e->chain->add(e->recent[(size_t)(t - e->t_base)], t == tb - 1, INT64_MAX, cs, wden, wden_hi, otab);
-            wden.push_back(1.f);
-            wden_hi.push_back(1.f);
-            otab.push_back(make_uint2(0u, 0u));
+                e->chain->add(e->recent[(size_t)(t - e->t_base)], INT64_MAX, cs, wden, wden_hi);
+            if (c.d.resample && kb > ka) c.build_res_tiles(ka, kb, res_tiles, res_otab);
+            while (wden.size() & 3) wden.push_back(1.f), wden_hi.push_back(1.f);
+            for (int i = 0; i < 4; ++i) wden.push_back(1.f), wden_hi.push_back(1.f);
         } else if (kb > ka) {
             st = c.build_tiles(e->recent, e->t_base, tb, ka, kb, (int32_t)e->t_base, tiles, wacc);
             if (st != PV_OK) return fail(st);
@@ -1450,7 +1503,8 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         const size_t o_b = o_a + (c.use_chain ? pad16(cs.size() * sizeof(ChainSlice)) : pad16(nP * 8));
         const size_t o_c = o_b + (c.use_chain ? pad16(wden.size() * 4) : pad16(tiles.size() * sizeof(OlaTile)));
         const size_t o_d = o_c + (c.use_chain ? (hi ? pad16(wden_hi.size() * 4) : 0) : pad16(wacc.size() * 4));
-        const size_t total = o_d + (c.use_chain ? pad16(otab.size() * sizeof(uint2)) : 0);
+        const size_t o_e = o_d + (c.use_chain ? pad16(res_tiles.size() * sizeof(ResTile)) : 0);
+        const size_t total = o_e + (c.use_chain ? pad16(res_otab.size() * sizeof(uint2)) : 0);
         if ((st = ensure_desc(e, total)) != PV_OK) return fail(st);
         char *hd = e->h_desc.p;
         int32_t *h_pinc = reinterpret_cast<int32_t *>(hd + o_pinc);
@@ -1459,7 +1513,8 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
             memcpy(hd + o_a, cs.data(), cs.size() * sizeof(ChainSlice));
             memcpy(hd + o_b, wden.data(), wden.size() * 4);
             if (hi) memcpy(hd + o_c, wden_hi.data(), wden_hi.size() * 4);
-            memcpy(hd + o_d, otab.data(), otab.size() * sizeof(uint2));
+            memcpy(hd + o_d, res_tiles.data(), res_tiles.size() * sizeof(ResTile));
+            memcpy(hd + o_e, res_otab.data(), res_otab.size() * sizeof(uint2));
         } else {
             int64_t *h_P = reinterpret_cast<int64_t *>(hd + o_a);
             for (size_t i = 0; i < nP; ++i) h_P[i] = e->recent[i].P;
@@ -1493,7 +1548,9 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
             cl.slices = reinterpret_cast<const ChainSlice *>(e->d_desc.p + o_a);
             cl.wden = reinterpret_cast<const float *>(e->d_desc.p + o_b);
             cl.wden_hi = hi ? reinterpret_cast<const float *>(e->d_desc.p + o_c) : cl.wden;
-            cl.otab = reinterpret_cast<const uint2 *>(e->d_desc.p + o_d);
+            cl.res_tiles = reinterpret_cast<const ResTile *>(e->d_desc.p + o_d);
+            cl.res_otab = reinterpret_cast<const uint2 *>(e->d_desc.p + o_e);
+            cl.res_ntiles = (int)res_tiles.size();
             cl.out = e->d_out.p;
         }
         c.launch_chunk(ia, ta, Tn, reinterpret_cast<const int32_t *>(e->d_desc.p + o_pinc),

@@ -182,46 +182,44 @@ struct OlaArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// Fused synthesis + overlap-add + resample ("chain" kernel): one workgroup per (stream, channel) row walks the
-// launch's slices in order with the reference's own streaming state -- the output accumulator
-// (synthesiseSlice / writeSlice, phasevocoderprocess.cc:1057-1073,1140-1194) as a ring in LDS, and behind it the
-// normalised overlap-add stream the Speex resampler reads (speex/resample.c:462-560) -- so the synthesis frames
-// never travel through HBM.  Wave w synthesises slices w, w + W, w + 2W, ... of the row; frames are added into
-// the accumulator strictly in slice order (a turn counter in LDS), which keeps the reference's summation order.
-// Everything about a slice that does not depend on the data is planned on the host, once for all rows.
+// Fused synthesis + overlap-add ("chain" kernel): one workgroup per (stream, channel) row walks the launch's slices
+// in order with the reference's own streaming state -- the output accumulator (synthesiseSlice / writeSlice,
+// phasevocoderprocess.cc:1057-1073,1140-1194) as a ring in LDS -- so the synthesis frames never travel through HBM.
+// Wave w synthesises slices w, w + W, w + 2W, ... of the row; frames are added into the accumulator strictly in
+// slice order (a turn counter in LDS), which keeps the reference's summation order.  What a slice completes,
+// [P_t, P_t + adv), is divided by its window sum and is the output (no resampling) or goes to a small per-row ring
+// in HBM from which pv_resample_kernel produces the output.  Everything about a slice that does not depend on the
+// data is planned on the host, once for all rows.
 // ---------------------------------------------------------------------------------------------------------------
 struct ChainSlice {
     int32_t acc_pos;  // (P_t mod AR): accumulator-ring position of the frame's first sample
-    int32_t str_pos;  // (P_t mod SR): stream-ring position of the first sample this slice finalises
+    int32_t str_pos;  // (P_t & smask): stream-ring position of the first sample this slice finalises
     int32_t adv;      // samples finalised after this slice's frame = its shift increment; 0 when the reference
                       // drops the slice (output ring full, phasevocoderprocess.cc:344-364): the frame stays in the
                       // accumulator and the next frame lands on the same position
-    int32_t wden_off; // offset of their window-sum denominators in ChainArgs::wden
-    int32_t k_off;    // first output this slice's wave emits, relative to ChainArgs::k_base
-    int32_t kcnt;     // outputs it emits (whole blocks of 64 while the launch goes on; see pv_engine.cc)
-    int32_t otab_off; // offset of those outputs' entries in ChainArgs::otab
+    int32_t wden_off; // offset of their window-sum denominators in ChainArgs::wden (laid out by ring quads: entry 0
+                      // belongs to sample P_t - (P_t mod 4))
+    int32_t k_off;    // not resampling: first output (= finalised sample) of the slice, relative to the launch's
+    int32_t kcnt;     // ... and how many of its samples are outputs (the CLI truncates the last ones)
     int32_t flags;    // bit 0: channels > 0 do not add this frame (CONSTANT-mode overrun: processOneSliceConstant
                       // returns after channel 0, phasevocoderprocess.cc:139-150)
+    int32_t pad;
 };
 
 struct ChainArgs {
     int N, rows, C, Tn;
     int AR;     // accumulator ring (floats, multiple of 4, >= N + 4)
-    int SR;     // stream ring (floats, multiple of 4); positions below `mirror` are also kept at SR + position,
-    int mirror; // so that a resampler window is one linear run of LDS
+    int smask;  // stream ring size - 1 (power of two minus one)
     int waves;  // W: waves per workgroup (= slices of a row in flight)
+    int diag;   // measurement builds only (AUDIOMOD_PV_CHAIN_DIAG, results are wrong when set): bit 2 no waiting for
+                // the turn, bit 3 no synthesis
     const ChainSlice *slices; // [Tn]
-    const float *wden;        // denominators, indexed wden_off + i
+    const float *wden;        // denominators, indexed wden_off + quad-relative sample
     const float *wden_hi;     // ... for channels > 0 (differs from wden only after a CONSTANT-mode overrun)
-    const uint2 *otab;        // per output: { stream-ring index of its first tap | sub-sample offset << 24,
-                              //               bits of the interpolation fraction }
-    float *st_acc;            // [rows][AR]          ring images carried between launches
-    float *st_str;            // [rows][SR + mirror]
-    // resampler (as OlaArgs)
-    int resample, interp, filt_len, oversample, sinc_len, tab_bytes;
-    const float *sinc;
-    const float4 *tab4;
-    // output
+    float *st_acc;            // [rows][AR] ring image carried between launches
+    float *stream;            // [rows][smask + 1] normalised overlap-add stream (resampling configurations)
+    int resample;
+    // output (not resampling)
     float *out;
     int64_t out_stride_row;
     // frame source when the synthesis runs as its own kernel (FFT sizes without a wave-per-frame transform)
@@ -229,6 +227,27 @@ struct ChainArgs {
     int FR;
     int64_t t0;
 };
+
+// pv_resample_kernel: one workgroup = 256 outputs of two rows
+struct ResTile {
+    int64_t k0;   // first output
+    int64_t n_lo; // first stream sample its windows need (negative: zero history)
+    int32_t kcnt; // outputs in the tile (<= kTileOut)
+    int32_t n_cnt; // stream samples it needs
+};
+struct ResArgs {
+    int rows, ntiles, smask;
+    const float *stream;
+    const ResTile *tiles;
+    const uint2 *otab; // [ntiles][kTileOut]: { first tap's offset in the tile | sub-sample offset << 16, fraction bits }
+    int interp, filt_len, oversample, sinc_len;
+    const float *sinc;
+    const float4 *tab4;
+    int lds_floats, tab_bytes;
+    float *out;
+    int64_t out_stride_row, k_base;
+};
+void launch_resample(const ResArgs &a, hipStream_t st);
 size_t chain_lds_bytes(const ChainArgs &a, int nc_wave /* 0: frames from HBM */);
 void launch_synth_chain(const SynthArgs &s, const ChainArgs &c, hipStream_t st); // nc 1024 / 2048
 void launch_frames_chain(const ChainArgs &c, hipStream_t st);                    // any size, frames from HBM

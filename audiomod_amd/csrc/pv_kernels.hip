@@ -1911,13 +1911,11 @@ void launch_ola(const OlaArgs &a, hipStream_t st) {
 //   synthesiseSlice (:1057,1073):  outputAccumulator[0..N) += frame         -> acc ring, frame t at P_t
 //   writeSlice (:1157-1194):       acc[0..s) /= wacc[0..s); resample or ring-write; shift both by s
 //                                  -> finalise [P_t, P_t + s): divide by the host-planned window sum (the
-//                                     denominator is data-independent), append to the stream ring, zero the slots
-//   resampler_basic_interpolate_single / _direct_single (speex/resample.c:462-560, 353-401)
-//                                  -> every output whose window the stream ring now holds
+//                                     denominator is data-independent), zero the slots; the normalised samples
+//                                     are the output, or go to a small HBM ring for pv_resample_kernel
 //
 // One workgroup per row; wave w owns slices w, w + W, ...: it synthesises its frame into its LDS region (or takes
-// the windowed frame from the HBM frame ring), waits for its turn, adds the frame, finalises, passes the turn on,
-// and resamples outside the turn.  Adds happen strictly in slice order, so every accumulator sample sees the
+// the windowed frame from the HBM frame ring), waits for its turn, adds the frame, finalises and passes the turn on.  Adds happen strictly in slice order, so every accumulator sample sees the
 // reference's sequence of float additions; a dropped slice (adv == 0) simply leaves its frame piled where it is.
 // There is no workgroup barrier inside the loop: waves drift apart and hide each other's latencies, the turn
 // counter only serialises the few hundred cycles of the add.
@@ -1928,20 +1926,16 @@ __device__ __forceinline__ float dpp_ror1(float v) { // lane i <- lane i - 1, la
 
 struct ChainLds {
     float *acc;   // [AR]
-    float *str;   // [SR + mirror]
-    char *tab;    // resampler coefficients
     int *turn;    // next slice whose frame may be added
 };
 __device__ __forceinline__ ChainLds chain_carve(const ChainArgs &c, char *base) {
     ChainLds l;
-    l.tab = base;
-    l.acc = reinterpret_cast<float *>(base + c.tab_bytes);
-    l.str = l.acc + c.AR;
-    l.turn = reinterpret_cast<int *>(l.str + c.SR + c.mirror);
+    l.acc = reinterpret_cast<float *>(base);
+    l.turn = reinterpret_cast<int *>(l.acc + c.AR);
     return l;
 }
 __host__ __device__ inline size_t chain_shared_bytes(const ChainArgs &c) {
-    return (size_t)c.tab_bytes + sizeof(float) * ((size_t)c.AR + c.SR + c.mirror) + 16;
+    return sizeof(float) * (size_t)c.AR + 16;
 }
 
 // ring images and coefficient table in, before the first slice (whole workgroup)
@@ -1949,17 +1943,6 @@ __device__ __forceinline__ void chain_prologue(const ChainArgs &c, const ChainLd
     const int nt = blockDim.x, tid = threadIdx.x;
     const float4 *sa = reinterpret_cast<const float4 *>(c.st_acc + (int64_t)row * c.AR);
     for (int i = tid; i < c.AR / 4; i += nt) reinterpret_cast<float4 *>(l.acc)[i] = sa[i];
-    const int sn = (c.SR + c.mirror) / 4;
-    const float4 *ss = reinterpret_cast<const float4 *>(c.st_str + (int64_t)row * (c.SR + c.mirror));
-    for (int i = tid; i < sn; i += nt) reinterpret_cast<float4 *>(l.str)[i] = ss[i];
-    if (c.resample) {
-        if (c.interp) {
-            const int cnt = c.oversample * (c.filt_len + 1);
-            for (int i = tid; i < cnt; i += nt) reinterpret_cast<float4 *>(l.tab)[i] = c.tab4[i];
-        } else {
-            for (int i = tid; i < c.sinc_len; i += nt) reinterpret_cast<float *>(l.tab)[i] = c.sinc[i];
-        }
-    }
     if (tid == 0) *l.turn = 0;
     __syncthreads();
 }
@@ -1968,25 +1951,22 @@ __device__ __forceinline__ void chain_epilogue(const ChainArgs &c, const ChainLd
     const int nt = blockDim.x, tid = threadIdx.x;
     float4 *sa = reinterpret_cast<float4 *>(c.st_acc + (int64_t)row * c.AR);
     for (int i = tid; i < c.AR / 4; i += nt) sa[i] = reinterpret_cast<const float4 *>(l.acc)[i];
-    const int sn = (c.SR + c.mirror) / 4;
-    float4 *ss = reinterpret_cast<float4 *>(c.st_str + (int64_t)row * (c.SR + c.mirror));
-    for (int i = tid; i < sn; i += nt) ss[i] = reinterpret_cast<const float4 *>(l.str)[i];
 }
 
-// What a wave fetches for its slice before it waits for its turn: the first 256 denominators and output-table
-// entries (the rest, for hops above 256 samples, are read in the loops).
+// What a wave fetches for its slice before it waits for its turn: the first 256 denominators (the rest, for hops
+// above 256 samples, are read in the loop).  The output-table entries are fetched after the turn has been passed
+// on: inside the turn they would only hold registers.
 struct ChainPrefetch {
     float wd[4];
-    uint2 oe[4];
 };
 __device__ __forceinline__ void chain_prefetch(const ChainArgs &c, const ChainSlice &sl, int row, int lane,
                                                ChainPrefetch &pf) {
-    const float *__restrict__ wden = (row % c.C) > 0 ? c.wden_hi : c.wden;
+    // (the denominators are laid out by ring quads: entry 0 belongs to sample P_t - r)
+    const float *__restrict__ wden = ((row % c.C) > 0 ? c.wden_hi : c.wden) + (sl.acc_pos & 3);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int i = lane + 64 * m;
         pf.wd[m] = wden[sl.wden_off + (i < sl.adv ? i : 0)];
-        pf.oe[m] = c.resample ? c.otab[sl.otab_off + (i < sl.kcnt ? i : 0)] : make_uint2(0u, 0u);
     }
 }
 
@@ -2011,28 +1991,40 @@ __device__ __forceinline__ void chain_add_pieces(float *acc, const int AQ, const
                                                  const int j0, const float4 (&A)[NP], float4 &prevR, const bool last) {
     float4 *acc4 = reinterpret_cast<float4 *>(acc);
     const int qend = NQ + (R_ ? 1 : 0); // quads the frame touches
-    auto step = [&](const int u, const float4 Aj) {
+    // The quads of a frame are distinct, so every read may be issued before the first write: the add is inside the
+    // turn, where a chain of read -> add -> write round trips per quad is time every other wave of the row waits.
+    constexpr int NS = NP + (R_ ? 1 : 0);
+    float4 V[NS];
+    auto quad_of = [&](int j) -> int { // ring quad of this lane's piece j, or -1 when it lies past the frame
+        const int u = lane + 64 * (j0 + j);
+        int qq = a + u;
+        if (qq >= AQ) qq -= AQ;
+        return (u < qend && (j < NP || last)) ? qq : -1;
+    };
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int qq = quad_of(j);
+        V[j] = acc4[qq >= 0 ? qq : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const float4 Aj = j < NP ? A[j < NP ? j : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 S = Aj;
         if (R_ != 0) {
             const float4 Rr = make_float4(dpp_ror1(Aj.x), dpp_ror1(Aj.y), dpp_ror1(Aj.z), dpp_ror1(Aj.w));
             const float4 P = lane == 0 ? prevR : Rr;
-            prevR = Rr;
+            if (j < NP) prevR = Rr;
             if (R_ == 1) S = make_float4(P.w, Aj.x, Aj.y, Aj.z);
             else if (R_ == 2) S = make_float4(P.z, P.w, Aj.x, Aj.y);
             else S = make_float4(P.y, P.z, P.w, Aj.x);
         }
-        if (u < qend) {
-            int q = a + u;
-            if (q >= AQ) q -= AQ;
-            float4 v = acc4[q];
-            v.x += S.x, v.y += S.y, v.z += S.z, v.w += S.w;
-            acc4[q] = v;
-        }
-    };
+        V[j].x += S.x, V[j].y += S.y, V[j].z += S.z, V[j].w += S.w;
+    }
 #pragma unroll
-    for (int j = 0; j < NP; ++j) step(lane + 64 * (j0 + j), A[j]);
-    // the quad behind the frame's last full one takes its final r samples (when the pieces end exactly there)
-    if (R_ != 0 && last) step(lane + 64 * (j0 + NP), make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int j = 0; j < NS; ++j) {
+        const int qq = quad_of(j);
+        if (qq >= 0) acc4[qq] = V[j];
+    }
 }
 template <int NP>
 __device__ __forceinline__ void chain_add_dispatch(float *acc, int AR, int acc_pos, int NQ, int lane, int j0,
@@ -2044,81 +2036,161 @@ __device__ __forceinline__ void chain_add_dispatch(float *acc, int AR, int acc_p
     else chain_add_pieces<3, NP>(acc, AQ, a, NQ, lane, j0, A, prevR, last);
 }
 
-template <int kRes> // -1 = from the arguments, 0 = none, 1 = direct sinc table, 2 = cubic-interpolated table
+template <int kRes> // 0 = the finalised samples are the output, 1 = they go to the stream ring of the resampler
 __device__ __forceinline__ void chain_finish_slice(const ChainArgs &c_in, const ChainLds &l, const ChainSlice &sl,
                                                    const ChainPrefetch &pf, const int row, const int tl, const int lane) {
     ChainArgs c = c_in;
-    if (kRes >= 0) c.resample = kRes != 0, c.interp = kRes == 2;
+    c.resample = kRes != 0;
     // ---- finalise [P_t, P_t + adv): acc / window sum -> stream ring (or straight out when nothing resamples)
-    const float *__restrict__ wden = (row % c.C) > 0 ? c.wden_hi : c.wden;
+    const float *__restrict__ wden = ((row % c.C) > 0 ? c.wden_hi : c.wden) + (sl.acc_pos & 3);
     float *__restrict__ out = c.out + (int64_t)row * c.out_stride_row + sl.k_off;
-    auto finalise = [&](int i, float wd) {
+    float *__restrict__ stream = c.stream + (int64_t)row * ((int64_t)c.smask + 1);
+    auto acc_index = [&](int i) {
         int ai = sl.acc_pos + i;
-        if (ai >= c.AR) ai -= c.AR;
-        const float v = l.acc[ai];
-        l.acc[ai] = 0.f;
-        const float y = v / wd;
+        return ai >= c.AR ? ai - c.AR : ai;
+    };
+    auto emit = [&](int i, float y) {
         if (c.resample) {
-            int si = sl.str_pos + i;
-            if (si >= c.SR) si -= c.SR;
-            l.str[si] = y;
-            if (si < c.mirror) l.str[si + c.SR] = y;
+            stream[(uint32_t)(sl.str_pos + i) & (uint32_t)c.smask] = y;
         } else if (i < sl.kcnt) {
             out[i] = y;
         }
     };
+    if (!(c.diag & 2)) {
+        // (all reads, then the divisions, then the writes: this is still inside the turn)
+        float v[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int i = lane + 64 * m;
-        if (i < sl.adv) finalise(i, pf.wd[m]);
+        for (int m = 0; m < 4; ++m) {
+            const int i = lane + 64 * m;
+            v[m] = i < sl.adv ? l.acc[acc_index(i)] : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int i = lane + 64 * m;
+            if (i < sl.adv) {
+                l.acc[acc_index(i)] = 0.f;
+                emit(i, v[m] / pf.wd[m]);
+            }
+        }
+        for (int i = 256 + lane; i < sl.adv; i += 64) {
+            const int ai = acc_index(i);
+            const float y = l.acc[ai] / wden[sl.wden_off + i];
+            l.acc[ai] = 0.f;
+            emit(i, y);
+        }
     }
-    for (int i = 256 + lane; i < sl.adv; i += 64) finalise(i, wden[sl.wden_off + i]);
     // ---- the next frame may be added now
     chain_pass_turn(l.turn, tl, lane);
-    if (!c.resample) return;
-    // ---- resample, outside the turn; a window is one linear run of the stream ring thanks to the mirror
-    const int NF = c.filt_len;
-    auto resample_one = [&](int o, uint2 oe) {
-        const float *x = l.str + (oe.x & 0xffffffu);
-        const int sub = (int)(oe.x >> 24);
-        if (c.interp) {
-            const float frac = __uint_as_float(oe.y);
-            const float4 *__restrict__ T = reinterpret_cast<const float4 *>(l.tab) + sub * (NF + 1);
-            v2f a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-#pragma unroll 4
-            for (int j = 0; j < NF; ++j) { // NF is a multiple of 4 (resample.c:687)
-                const float4 cc = T[j];
-                const v2f c01 = {cc.x, cc.y}, c23 = {cc.z, cc.w};
-                const float xv = x[j];
-                const v2f xx = {xv, xv};
-                a01 += xx * c01; // -ffp-contract=off: separate multiply and add, like the reference
-                a23 += xx * c23;
+}
+
+// The wave-FFT kernel's version of "wait, add, finalise, pass the turn".  Everything that does not need the
+// accumulator happens before the wait (the frame shifted to the ring's quad alignment, the denominators fetched),
+// and inside the turn a lane reads its quads, adds, and writes them back once -- zeros where a sample belongs to
+// [P_t, P_t + adv), which this frame completes (writeSlice's divide + shift, :1157-1194): those sums stay in the
+// lane's registers and are normalised and appended to the stream after the turn has been passed on.  The second
+// counter publishes, in slice order, that a slice's stream samples are written (the next slice's wave resamples the
+// outputs this one deferred).  wden is laid out by ring quads: entry 0 belongs to sample P_t - r.
+template <int R_, int NP, int kRes>
+__device__ __forceinline__ void chain_slice_tail(const ChainArgs &c_in, const ChainLds &l, const ChainSlice &sl,
+                                                 const float4 (&A)[NP], const bool skip, const int row, const int tl,
+                                                 const int lane) {
+    ChainArgs c = c_in;
+    c.resample = kRes != 0;
+    constexpr int NS = NP + (R_ ? 1 : 0);
+    const int AQ = c.AR >> 2, a = sl.acc_pos >> 2;
+    float4 *acc4 = reinterpret_cast<float4 *>(l.acc);
+    // ---- before the turn
+    float4 S[NS];
+    {
+        float4 prevR = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const float4 Aj = j < NP ? A[j < NP ? j : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+            S[j] = Aj;
+            if (R_ != 0) {
+                const float4 Rr = make_float4(dpp_ror1(Aj.x), dpp_ror1(Aj.y), dpp_ror1(Aj.z), dpp_ror1(Aj.w));
+                const float4 P = lane == 0 ? prevR : Rr;
+                prevR = Rr;
+                if (R_ == 1) S[j] = make_float4(P.w, Aj.x, Aj.y, Aj.z);
+                else if (R_ == 2) S[j] = make_float4(P.z, P.w, Aj.x, Aj.y);
+                else S[j] = make_float4(P.y, P.z, P.w, Aj.x);
             }
-            // cubic_coef (resample.c:339-351)
-            const float c0 = -0.16667f * frac + 0.16667f * frac * frac * frac;
-            const float c1 = frac + 0.5f * frac * frac - 0.5f * frac * frac * frac;
-            const float c3 = -0.33333f * frac + 0.5f * frac * frac - 0.16667f * frac * frac * frac;
-            const float c2 = (float)(1. - c0 - c1 - c3);
-            out[o] = (c0 * a01.x) + (c1 * a01.y) + (c2 * a23.x) + (c3 * a23.y);
-        } else {
-            const float *t = reinterpret_cast<const float *>(l.tab) + sub * NF;
-            float sum = 0.f;
-            for (int j = 0; j < NF; ++j) sum += x[j] * t[j];
-            out[o] = sum;
+        }
+    }
+    const float *__restrict__ wden = ((row % c.C) > 0 ? c.wden_hi : c.wden) + sl.wden_off;
+    const int fin_quads = (sl.adv + R_ + 3) >> 2; // quads that hold samples of the region being finalised
+    float4 wd[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int u = lane + 64 * j;
+        wd[j] = *reinterpret_cast<const float4 *>(wden + 4 * (u < fin_quads ? u : 0));
+    }
+    int q[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int qq = a + lane + 64 * j;
+        q[j] = qq >= AQ ? qq - AQ : qq;
+    }
+    const bool tail_lane = lane == 0; // the quad behind the last full piece belongs to one lane
+    // zero goes back where a sample is inside [0, adv) relative to P_t
+    auto write_back = [&](int j, const float4 v) -> float4 {
+        const int s0 = 4 * (lane + 64 * j) - R_;
+        float4 wb = v;
+        if (256 * j - R_ < sl.adv) { // wave-uniform: this piece reaches into the region
+            wb.x = (s0 >= 0 && s0 < sl.adv) ? 0.f : v.x;
+            wb.y = (s0 + 1 >= 0 && s0 + 1 < sl.adv) ? 0.f : v.y;
+            wb.z = (s0 + 2 >= 0 && s0 + 2 < sl.adv) ? 0.f : v.z;
+            wb.w = (s0 + 3 < sl.adv) ? 0.f : v.w;
+        }
+        return wb;
+    };
+    // ---- the turn
+    if (!(c.diag & 4)) chain_wait_turn(l.turn, tl);
+    float4 V[NS];
+    if (!skip) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) V[j] = acc4[q[j]];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            V[j].x += S[j].x, V[j].y += S[j].y, V[j].z += S[j].z, V[j].w += S[j].w;
+            if (j < NP || tail_lane) acc4[q[j]] = write_back(j, V[j]);
+        }
+    } else {
+        // a frame this channel does not add (CONSTANT-mode overrun): adv is 0 then, nothing is finalised either
+#pragma unroll
+        for (int j = 0; j < NS; ++j) V[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    chain_pass_turn(l.turn, tl, lane);
+    // ---- after the turn: normalise the finalised samples and append them to the stream (or emit them)
+    float *__restrict__ out = c.out + (int64_t)row * c.out_stride_row + sl.k_off;
+    float *__restrict__ stream = c.stream + (int64_t)row * ((int64_t)c.smask + 1);
+    auto emit = [&](int sidx, float y) { // sidx: sample index relative to P_t
+        if (sidx < 0 || sidx >= sl.adv) return;
+        if (c.resample) {
+            stream[(uint32_t)(sl.str_pos + sidx) & (uint32_t)c.smask] = y;
+        } else if (sidx < sl.kcnt) {
+            out[sidx] = y;
         }
     };
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int o = lane + 64 * m;
-        if (64 * m < sl.kcnt) { // wave-uniform
-            if (o < sl.kcnt) resample_one(o, pf.oe[m]);
+    for (int j = 0; j < NS; ++j) {
+        if (256 * j - R_ < sl.adv) { // wave-uniform
+            const int u = lane + 64 * j;
+            const float4 d = j < 2 ? wd[j < 2 ? j : 0]
+                                   : *reinterpret_cast<const float4 *>(wden + 4 * (u < fin_quads ? u : 0));
+            const int s0 = 4 * u - R_;
+            if (j < NP || tail_lane) {
+                emit(s0, V[j].x / d.x);
+                emit(s0 + 1, V[j].y / d.y);
+                emit(s0 + 2, V[j].z / d.z);
+                emit(s0 + 3, V[j].w / d.w);
+            }
         }
     }
-    for (int o = 256 + lane; o < sl.kcnt; o += 64) resample_one(o, c.otab[sl.otab_off + o]);
 }
 
 template <int NC, int kPlainCore, int kRes>
-__global__ __launch_bounds__(NC == 1024 ? 896 : 512) void pv_synth_chain_kernel(const SynthArgs s, const ChainArgs c) {
+__global__ __launch_bounds__(NC == 1024 ? 1024 : 512) void pv_synth_chain_kernel(const SynthArgs s, const ChainArgs c) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using W = WF<NC>;
     constexpr int N = 2 * NC, hs = NC, NQ = N / 4, NP = NQ / 64;
@@ -2139,7 +2211,7 @@ __global__ __launch_bounds__(NC == 1024 ? 896 : 512) void pv_synth_chain_kernel(
         const bool skip = (sl.flags & 1) && upper; // wave-uniform
         float4 A[NP];
         if (!skip) {
-            synth_wave_role<NC, kPlainCore, 1>(s, row, tl, wlds, lane);
+            if (!(c.diag & 8)) synth_wave_role<NC, kPlainCore, 1>(s, row, tl, wlds, lane);
             // ifftshift + synthesis window (phasevocoderimpl.h:183-198): four consecutive samples per lane and piece
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
@@ -2150,22 +2222,18 @@ __global__ __launch_bounds__(NC == 1024 ? 896 : 512) void pv_synth_chain_kernel(
                 A[j] = make_float4(z0.x * ww.x, z0.y * ww.y, z1.x * ww.z, z1.y * ww.w);
             }
         }
-        ChainPrefetch pf;
-        chain_prefetch(c, sl, row, lane, pf);
-        chain_wait_turn(l.turn, tl);
-        if (!skip) {
-            float4 prevR = make_float4(0.f, 0.f, 0.f, 0.f);
-            chain_add_dispatch<NP>(l.acc, c.AR, sl.acc_pos, NQ, lane, 0, A, prevR, true);
-            wave_sync();
-        }
-        chain_finish_slice<kRes>(c, l, sl, pf, row, tl, lane);
+        const int r = sl.acc_pos & 3; // wave-uniform
+        if (r == 0) chain_slice_tail<0, NP, kRes>(c, l, sl, A, skip, row, tl, lane);
+        else if (r == 1) chain_slice_tail<1, NP, kRes>(c, l, sl, A, skip, row, tl, lane);
+        else if (r == 2) chain_slice_tail<2, NP, kRes>(c, l, sl, A, skip, row, tl, lane);
+        else chain_slice_tail<3, NP, kRes>(c, l, sl, A, skip, row, tl, lane);
     }
     chain_epilogue(c, l, row);
 }
 
 // Any FFT size: the synthesis kernel has written the windowed frames to the HBM frame ring; the chain takes them
 // from there, up to eight pieces (2048 samples) at a time.
-template <int kRes> __global__ __launch_bounds__(896) void pv_frames_chain_kernel(const ChainArgs c) {
+template <int kRes> __global__ __launch_bounds__(1024) void pv_frames_chain_kernel(const ChainArgs c) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = blockIdx.x;
@@ -2225,16 +2293,13 @@ template <typename K> static void allow_big_lds_dev(K kernel, unsigned long long
 template <int NC, int kPlainCore> static void launch_synth_chain_res(const SynthArgs &s, const ChainArgs &c, hipStream_t st) {
     const size_t lds = chain_lds_bytes(c, NC);
     const dim3 grid(c.rows), block(64 * c.waves);
-    static unsigned long long m0 = 0, m1 = 0, m2 = 0;
+    static unsigned long long m0 = 0, m1 = 0;
     if (!c.resample) {
         allow_big_lds_dev(pv_synth_chain_kernel<NC, kPlainCore, 0>, m0);
         hipLaunchKernelGGL((pv_synth_chain_kernel<NC, kPlainCore, 0>), grid, block, lds, st, s, c);
-    } else if (!c.interp) {
+    } else {
         allow_big_lds_dev(pv_synth_chain_kernel<NC, kPlainCore, 1>, m1);
         hipLaunchKernelGGL((pv_synth_chain_kernel<NC, kPlainCore, 1>), grid, block, lds, st, s, c);
-    } else {
-        allow_big_lds_dev(pv_synth_chain_kernel<NC, kPlainCore, 2>, m2);
-        hipLaunchKernelGGL((pv_synth_chain_kernel<NC, kPlainCore, 2>), grid, block, lds, st, s, c);
     }
 }
 
@@ -2257,16 +2322,101 @@ void launch_synth_chain(const SynthArgs &s, const ChainArgs &c, hipStream_t st) 
 void launch_frames_chain(const ChainArgs &c, hipStream_t st) {
     const size_t lds = chain_lds_bytes(c, 0);
     const dim3 grid(c.rows), block(64 * c.waves);
-    static unsigned long long m0 = 0, m1 = 0, m2 = 0;
+    static unsigned long long m0 = 0, m1 = 0;
     if (!c.resample) {
         allow_big_lds_dev(pv_frames_chain_kernel<0>, m0);
         hipLaunchKernelGGL(pv_frames_chain_kernel<0>, grid, block, lds, st, c);
-    } else if (!c.interp) {
+    } else {
         allow_big_lds_dev(pv_frames_chain_kernel<1>, m1);
         hipLaunchKernelGGL(pv_frames_chain_kernel<1>, grid, block, lds, st, c);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Speex resampling of the normalised overlap-add stream (the fused path's second kernel): a tile of 256 outputs of
+// two rows; the samples its windows cover are one contiguous run of each row's stream ring, copied to LDS, then every
+// thread runs resampler_basic_interpolate_single / resampler_basic_direct_single (speex/resample.c:462-560, 353-401)
+// for the same output of both rows, so that a tap's coefficients are read once for two outputs (all rows share one
+// schedule).  Separate multiply and add (-ffp-contract=off), tap order and accumulators as in the reference.
+// --------------------------------------------------------------------------------------------
+template <int kRes> // 1 = direct sinc table, 2 = cubic-interpolated table
+__global__ __launch_bounds__(kTileOut) void pv_resample_kernel(const ResArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NR = 2;
+    float4 *tab4 = reinterpret_cast<float4 *>(smem_raw);
+    float *stab = reinterpret_cast<float *>(smem_raw);
+    float *xs = reinterpret_cast<float *>(smem_raw + a.tab_bytes); // [NR][lds_floats]
+    const int nt = blockDim.x, tid = threadIdx.x;
+    const ResTile tile = a.tiles[blockIdx.x];
+    const int row0 = blockIdx.y * NR, NF = a.filt_len;
+    const int nr = a.rows - row0 < NR ? a.rows - row0 : NR;
+    uint2 oe = make_uint2(0u, 0u);
+    if (tid < tile.kcnt) oe = a.otab[(int64_t)blockIdx.x * kTileOut + tid];
+    if (kRes == 2) {
+        const int cnt = a.oversample * (NF + 1);
+        for (int i = tid; i < cnt; i += nt) tab4[i] = a.tab4[i];
     } else {
-        allow_big_lds_dev(pv_frames_chain_kernel<2>, m2);
-        hipLaunchKernelGGL(pv_frames_chain_kernel<2>, grid, block, lds, st, c);
+        for (int i = tid; i < a.sinc_len; i += nt) stab[i] = a.sinc[i];
+    }
+    for (int r = 0; r < nr; ++r) {
+        const float *__restrict__ st = a.stream + (int64_t)(row0 + r) * ((int64_t)a.smask + 1);
+        for (int i = tid; i < tile.n_cnt; i += nt) {
+            const int64_t n = tile.n_lo + i; // the stream is zero before its first sample (skip_zeros, :1225)
+            xs[r * a.lds_floats + i] = n >= 0 ? st[(uint32_t)n & (uint32_t)a.smask] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (tid >= tile.kcnt) return;
+    float *__restrict__ out = a.out + (int64_t)row0 * a.out_stride_row + (tile.k0 - a.k_base) + tid;
+    const float *x = xs + (int)(oe.x & 0xffffu); // tap j = 0
+    if (kRes == 2) {
+        const float frac = __uint_as_float(oe.y);
+        const float4 *__restrict__ T = tab4 + (int)(oe.x >> 16) * (NF + 1);
+        v2f a01[NR], a23[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) a01[r] = v2f{0.f, 0.f}, a23[r] = v2f{0.f, 0.f};
+#pragma unroll 4
+        for (int j = 0; j < NF; ++j) { // NF is a multiple of 4 (resample.c:687)
+            const float4 c = T[j];
+            const v2f c01 = {c.x, c.y}, c23 = {c.z, c.w};
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const float xv = x[r * a.lds_floats + j]; // a missing second row reads stale LDS: never stored
+                const v2f xx = {xv, xv};
+                a01[r] += xx * c01;
+                a23[r] += xx * c23;
+            }
+        }
+        // cubic_coef (resample.c:339-351)
+        const float c0 = -0.16667f * frac + 0.16667f * frac * frac * frac;
+        const float c1 = frac + 0.5f * frac * frac - 0.5f * frac * frac * frac;
+        const float c3 = -0.33333f * frac + 0.5f * frac * frac - 0.16667f * frac * frac * frac;
+        const float c2 = (float)(1. - c0 - c1 - c3);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (r < nr)
+                out[(int64_t)r * a.out_stride_row] = (c0 * a01[r].x) + (c1 * a01[r].y) + (c2 * a23[r].x) + (c3 * a23[r].y);
+    } else {
+        const float *t = stab + (oe.x >> 16) * (uint32_t)NF;
+        for (int r = 0; r < nr; ++r) {
+            float sum = 0.f;
+            for (int j = 0; j < NF; ++j) sum += x[r * a.lds_floats + j] * t[j];
+            out[(int64_t)r * a.out_stride_row] = sum;
+        }
+    }
+}
+
+void launch_resample(const ResArgs &a, hipStream_t st) {
+    if (a.ntiles <= 0) return;
+    const size_t lds = (size_t)a.tab_bytes + sizeof(float) * (size_t)a.lds_floats * 2;
+    const dim3 grid(a.ntiles, (a.rows + 1) / 2);
+    static unsigned long long m1 = 0, m2 = 0;
+    if (a.interp) {
+        allow_big_lds_dev(pv_resample_kernel<2>, m2);
+        hipLaunchKernelGGL(pv_resample_kernel<2>, grid, dim3(kTileOut), lds, st, a);
+    } else {
+        allow_big_lds_dev(pv_resample_kernel<1>, m1);
+        hipLaunchKernelGGL(pv_resample_kernel<1>, grid, dim3(kTileOut), lds, st, a);
     }
 }
 

@@ -340,9 +340,15 @@ def main():
         for k, (ms, n) in ktimes.items():
             if n:
                 per_kernel[k] = {"avg_ms": round(ms / n, 4), "samples": int(n)}
-        if "pv_synth_ola_kernel" in per_kernel:  # fused path: one kernel for the last two stages
-            stages["synthesis+ola_resample"] = (stages["synthesis"][0] + stages["ola_resample"][0],
-                                                ["pv_synth_ola_kernel"])
+        if "pv_synth_ola_kernel" in per_kernel:
+            # fused path: synthesis + overlap-add in one kernel (frames never leave LDS); where the configuration
+            # resamples, pv_ola_kernel is the resampling kernel that follows it.  The fused kernel carries the
+            # synthesis stage's bytes and the overlap-add's N + s; the resampler its s + h.
+            stages["synthesis"] = (4 * (2 * H + N) + 4 * (N + s), ["pv_synth_ola_kernel"])
+            if rs:
+                stages["ola_resample"] = (4 * (s + h), ["pv_ola_kernel"])
+            else:
+                del stages["ola_resample"]
         traffic_db = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):

@@ -58,6 +58,39 @@ ALLOBJ := $(patsubst $(REF)/%.cc,$(OUT)/obj/%.o,$(ALLCXX))
 $(OUT)/audiomod-exe: $(ALLOBJ) $(COBJ)
 	$(CXX) $(CXXFLAGS) $(ALLOBJ) $(COBJ) -o $@ -static-libstdc++ -static-libgcc -lpthread -ldl
 
+# ---------------------------------------------------------------------------------------------------------
+# "Drops into audiomod-exe unchanged", as a build: the reference's own main/main.cc + wavfile.cc and every
+# non-phase-vocoder effect, compiled from where they lie, linked against THIS repository's audiomod::phasevocoder
+# (audiomod_amd/csrc/phasevocoder.cc over libaudiomod_pv.so) instead of src/phasevocoder/*.  What a maintainer
+# changes is one header: include/dafx/phasevocoder.h.  The reference headers include each other by quoted paths
+# relative to themselves, so that swap is materialised as a tree of symlinks ($(OUT)/dropin/include: every
+# reference header except that one, which points at ours) -- no reference file is copied or edited.
+# tests/test_dropin_exe.py runs the result on the GPU box against the reference CLI's golden WAV files.
+# ---------------------------------------------------------------------------------------------------------
+DROPIN := $(OUT)/dropin
+REPO   := $(abspath .)
+NONPV_OBJ := $(filter-out $(OUT)/obj/src/phasevocoder/%,$(filter-out $(OUT)/obj/main/%,$(ALLOBJ)))
+$(DROPIN)/include/.stamp: include/dafx/phasevocoder.h
+	@rm -rf $(DROPIN)/include && mkdir -p $(DROPIN)/include/dafx $(DROPIN)/include/analyzer
+	@for f in $(REF)/include/*.h; do ln -s $$f $(DROPIN)/include/; done
+	@for f in $(REF)/include/analyzer/*.h; do ln -s $$f $(DROPIN)/include/analyzer/; done
+	@for f in $(REF)/include/dafx/*.h; do [ "$$(basename $$f)" = phasevocoder.h ] || ln -s $$f $(DROPIN)/include/dafx/; done
+	@ln -s $(REPO)/include/dafx/phasevocoder.h $(DROPIN)/include/dafx/phasevocoder.h
+	@touch $@
+DROPIN_INC := -I$(DROPIN)/include -I$(DROPIN)/include/dafx -I$(DROPIN)/include/analyzer -I$(REF)/src
+$(DROPIN)/main.o: $(REF)/main/main.cc $(DROPIN)/include/.stamp
+	$(CXX) $(CXXFLAGS) $(DROPIN_INC) -c $< -o $@
+$(DROPIN)/wavfile.o: $(REF)/main/wavfile.cc $(DROPIN)/include/.stamp
+	$(CXX) $(CXXFLAGS) $(DROPIN_INC) -c $< -o $@
+$(DROPIN)/phasevocoder_shim.o: audiomod_amd/csrc/phasevocoder.cc $(DROPIN)/include/.stamp include/audiomod_pv.h
+	$(CXX) $(CXXFLAGS) -std=gnu++17 $(DROPIN_INC) -Iinclude -c $< -o $@
+$(OUT)/audiomod-exe-mi355x: $(DROPIN)/main.o $(DROPIN)/wavfile.o $(DROPIN)/phasevocoder_shim.o $(NONPV_OBJ) $(COBJ) audiomod_amd/lib/libaudiomod_pv.so
+	$(CXX) $(CXXFLAGS) $(DROPIN)/main.o $(DROPIN)/wavfile.o $(DROPIN)/phasevocoder_shim.o $(NONPV_OBJ) $(COBJ) \
+	    -Laudiomod_amd/lib -laudiomod_pv -Wl,-rpath,'$$ORIGIN/../../audiomod_amd/lib' -Wl,-rpath-link,/opt/rocm/lib \
+	    -o $@ -lpthread -ldl
+dropin: $(OUT)/audiomod-exe-mi355x
+all: dropin
+
 clean:
 	rm -rf $(OUT)
-.PHONY: all clean
+.PHONY: all clean dropin

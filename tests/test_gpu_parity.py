@@ -587,13 +587,13 @@ np.savez(sys.argv[1], *outs)
 
 
 OVERRUN_GPU = [
-    (dict(semitones=-3.0), 2, [30000, 480, 480, 20000, 480, 480]),
+    (dict(semitones=-3.0), 2, [100000, 480, 480, 50000, 480, 480]),
     (dict(semitones=5.0, fftsize=256), 2, [6000, 6000, 64, 6000]),
     (dict(mode="constant", fftsize=256), 3, [4800, 4800, 64, 9000, 480]),
     (dict(mode="vocoder", fftsize=512), 1, [9000, 480, 9000]),
     (dict(mode="time_stretch", time_ratio=2.5, fftsize=512, coremode=0), 2, [12000, 100, 12000]),
     (dict(mode="robotic", fftsize=1024, semitones=-9.0), 2, [40000, 480]),
-    (dict(semitones=4.0, fftsize=4096, coremode=2), 2, [70000, 3000]),
+    (dict(semitones=4.0, fftsize=4096, coremode=2), 2, [130000, 3000]),
 ]
 
 
