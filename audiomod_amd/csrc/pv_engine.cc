@@ -181,6 +181,12 @@ struct ChainLaunch {
     const ResTile *res_tiles;
     const uint2 *res_otab;
     int res_ntiles;
+    // Batch path: the resampling kernel (arithmetic-bound) runs on its own stream beside what the main stream does
+    // next (the following chunk's analysis and match, memory- and latency-bound).  ev_fused: recorded behind this
+    // launch's fused kernel; ev_res: recorded behind its resampling; ev_ring_free: the resampling that must have
+    // finished before this launch's fused kernel may overwrite the stream ring (two launches back).
+    hipStream_t res_stream;
+    hipEvent_t ev_fused, ev_res, ev_ring_free;
 };
 
 struct Core {
@@ -840,6 +846,8 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ra.out = out;
         ra.out_stride_row = out_stride_row;
         ra.k_base = k_base;
+        if (d.resample && chain->res_stream && chain->ev_ring_free)
+            (void)hipStreamWaitEvent(st, chain->ev_ring_free, 0);
         if (wave_fft()) {
             // synthesis and overlap-add in one kernel: the frames stay in LDS
             rec(2 * PV_K_SYNTH_OLA);
@@ -853,7 +861,14 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
             launch_frames_chain(ca, st);
             if (!d.resample) rec(2 * PV_K_OLA_RESAMPLE + 1);
         }
-        if (d.resample) {
+        if (d.resample && chain->res_stream) {
+            (void)hipEventRecord(chain->ev_fused, st);
+            (void)hipStreamWaitEvent(chain->res_stream, chain->ev_fused, 0);
+            if (ev && wave_fft()) (void)hipEventRecord(ev[2 * PV_K_OLA_RESAMPLE], chain->res_stream);
+            launch_resample(ra, chain->res_stream);
+            if (ev) (void)hipEventRecord(ev[2 * PV_K_OLA_RESAMPLE + 1], chain->res_stream);
+            (void)hipEventRecord(chain->ev_res, chain->res_stream);
+        } else if (d.resample) {
             if (wave_fft()) rec(2 * PV_K_OLA_RESAMPLE);
             launch_resample(ra, st);
             rec(2 * PV_K_OLA_RESAMPLE + 1);
@@ -958,6 +973,8 @@ struct pv_batch {
     DevBuf<float> d_carrier; // vocoder modes: the carrier signal for every sample fed (incl. the zero flush)
     hipStream_t chain_stream = nullptr; // second HIP stream for the rotation chain (phase-locked mode)
     hipEvent_t ev_match[4] = {}, ev_chain[4] = {};
+    hipStream_t res_stream = nullptr;   // fused path, resampling configurations: the resampling kernel's stream
+    hipEvent_t ev_fused[4] = {}, ev_res[4] = {};
     int timing = 0; // 0 = off, n = instrument every n-th chunk
     std::vector<hipEvent_t> ev_pool; // kEvPerChunk per instrumented chunk
     std::vector<int> ev_chunk;       // chunk index of each used pool segment
@@ -969,7 +986,10 @@ struct pv_batch {
         for (int i = 0; i < 4; ++i) {
             if (ev_match[i]) (void)hipEventDestroy(ev_match[i]);
             if (ev_chain[i]) (void)hipEventDestroy(ev_chain[i]);
+            if (ev_fused[i]) (void)hipEventDestroy(ev_fused[i]);
+            if (ev_res[i]) (void)hipEventDestroy(ev_res[i]);
         }
+        if (res_stream) (void)hipStreamDestroy(res_stream);
         if (chain_stream) (void)hipStreamDestroy(chain_stream);
     }
 };
@@ -1166,6 +1186,19 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
             HIPC(hipEventCreateWithFlags(&b->ev_chain[i], hipEventDisableTiming));
         }
     }
+    if (c.use_chain && c.d.resample) {
+        // AUDIOMOD_PV_RES_STREAM=1: the resampling kernel on a stream of its own, beside the next chunk's analysis.
+        // Measured: no gain -- both kernels slow down by more than the overlap returns (63.2 vs 60.8 ms per step) --
+        // so it is off unless asked for.
+        const char *e = getenv("AUDIOMOD_PV_RES_STREAM");
+        if (e && atoi(e) != 0) {
+            HIPC(hipStreamCreateWithFlags(&b->res_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 4; ++i) {
+                HIPC(hipEventCreateWithFlags(&b->ev_fused[i], hipEventDisableTiming));
+                HIPC(hipEventCreateWithFlags(&b->ev_res[i], hipEventDisableTiming));
+            }
+        }
+    }
     if (c.d.vocoder) {
         CarrierGen gen((float)c.d.cfg.sample_rate, c.d.chord);
         std::vector<float> car((size_t)b->plan.in_frames);
@@ -1261,6 +1294,10 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
             cl.res_tiles = b->d_res_tiles.p + ch.res_begin;
             cl.res_otab = b->d_res_otab.p + (size_t)ch.res_begin * kTileOut;
             cl.res_ntiles = ch.res_ntiles;
+            cl.res_stream = b->res_stream;
+            cl.ev_fused = b->ev_fused[ci & 3];
+            cl.ev_res = b->ev_res[ci & 3];
+            cl.ev_ring_free = ci >= 2 ? b->ev_res[(ci - 2) & 3] : nullptr;
             cl.out = d_out + ch.k0;
         }
         c.launch_chunk(ia, ch.t0, ch.Tn, b->d_pinc.p + ch.t0, b->d_tiles.p + ch.tile_begin, ch.ntiles, b->d_P.p,
@@ -1283,6 +1320,9 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
     } else {
         for (size_t ci = 0; ci < nchunks; ++ci) launch(ci, events_for(ci), 0);
     }
+    if (b->res_stream && c.use_chain) // the caller synchronises `st`: it has to cover the resampling stream too
+        for (size_t ci = nchunks > 2 ? nchunks - 2 : 0; ci < nchunks; ++ci)
+            HIPC(hipStreamWaitEvent(st, b->ev_res[ci & 3], 0));
     HIPC(hipGetLastError());
     return PV_OK;
 }

@@ -20,10 +20,12 @@
 //
 // Arithmetic contract: this file is compiled with -ffp-contract=off.  Every float expression
 // keeps the reference's operand order and rounding points so the FFT, magnitudes, peak picking,
-// OLA and resampler MACs are bit-identical to the x86 reference; only atan2f/sinf/cosf differ
-// (device libm, a few ulp).  princarg stays in double with a true IEEE divide, as the reference
+// OLA and resampler MACs are bit-identical to the x86 reference.  The analysis phases are too: atan2f is libm's own
+// algorithm (pv_atan2f.h), because the phase propagation is discontinuous in them.  Only sinf / cosf come from the
+// device libm (a few ulp; the output is continuous in them).  princarg stays in double with a true IEEE divide, as the reference
 // (common/system/sys.h:84,91).
 #include "pv_kernels.h"
+#include "pv_atan2f.h"
 #include "pv_wavefft.h"
 
 #include <hip/hip_runtime.h>
@@ -196,10 +198,10 @@ __global__ __launch_bounds__(kFftThreads) void pv_analyze_kernel(const AnalyzeAr
             const float m0 = sqrtf(r0 * r0 + 0.f * 0.f), mn = sqrtf(rn * rn + 0.f * 0.f);
             mag[0] = m0;
             smag[0] = m0;
-            ph[0] = atan2f(0.f, r0);
+            ph[0] = pv_atan2f_fd(0.f, r0);
             mag[nc] = mn;
             smag[nc] = mn;
-            ph[nc] = atan2f(0.f, rn);
+            ph[nc] = pv_atan2f_fd(0.f, rn);
         } else {
             const float2 fpk = buf[k];
             const float2 q = buf[nc - k];
@@ -213,12 +215,12 @@ __global__ __launch_bounds__(kFftThreads) void pv_analyze_kernel(const AnalyzeAr
                 const float m = sqrtf(xr * xr + xi * xi);
                 mag[k] = m;
                 smag[k] = m;
-                ph[k] = atan2f(xi, xr);
+                ph[k] = pv_atan2f_fd(xi, xr);
             }
             const float m2 = sqrtf(yr * yr + yi * yi);
             mag[nc - k] = m2;
             smag[nc - k] = m2;
-            ph[nc - k] = atan2f(yi, yr);
+            ph[nc - k] = pv_atan2f_fd(yi, yr);
         }
     }
     if (!a.find_peaks) return;
@@ -381,8 +383,8 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
             const float r0 = tdc.x + tdc.y, rn = tdc.x - tdc.y;
             mlo[0] = sqrtf(r0 * r0 + 0.f * 0.f);
             mhi[0] = sqrtf(rn * rn + 0.f * 0.f);
-            plo[0] = atan2f(0.f, r0);
-            phi[0] = atan2f(0.f, rn);
+            plo[0] = pv_atan2f_fd(0.f, r0);
+            phi[0] = pv_atan2f_fd(0.f, rn);
         } else {
             const cf fpk = lds[W::pad(k)];
             const cf q = lds[W::pad(NC - k)];
@@ -394,8 +396,8 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
             const float yr = (f1k.x - tq.x) * 0.5f, yi = (tq.y - f1k.y) * 0.5f;
             mlo[j] = sqrtf(xr * xr + xi * xi);
             mhi[j] = sqrtf(yr * yr + yi * yi);
-            plo[j] = atan2f(xi, xr);
-            phi[j] = atan2f(yi, yr);
+            plo[j] = pv_atan2f_fd(xi, xr);
+            phi[j] = pv_atan2f_fd(yi, yr);
         }
     }
     float mmid = 0.f, pmid = 0.f;
@@ -407,7 +409,7 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
         const cf tq = wf_cmul(f2k, swmid);
         const float yr = (f1k.x - tq.x) * 0.5f, yi = (tq.y - f1k.y) * 0.5f;
         mmid = sqrtf(yr * yr + yi * yi);
-        pmid = atan2f(yi, yr);
+        pmid = pv_atan2f_fd(yi, yr);
     }
     // Out through the (now free) wave-private LDS region: a lane holds bins k and NC - k, the planes want runs of
     // consecutive bins, and stores are issue-bound -- four 16-byte stores per lane and plane instead of sixteen
@@ -2339,10 +2341,12 @@ void launch_frames_chain(const ChainArgs &c, hipStream_t st) {
 // for the same output of both rows, so that a tap's coefficients are read once for two outputs (all rows share one
 // schedule).  Separate multiply and add (-ffp-contract=off), tap order and accumulators as in the reference.
 // --------------------------------------------------------------------------------------------
+constexpr int kResRows = 4; // rows per workgroup of the resampling kernel: a tap's coefficients are read once for all
+
 template <int kRes> // 1 = direct sinc table, 2 = cubic-interpolated table
 __global__ __launch_bounds__(kTileOut) void pv_resample_kernel(const ResArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int NR = 2;
+    constexpr int NR = kResRows;
     float4 *tab4 = reinterpret_cast<float4 *>(smem_raw);
     float *stab = reinterpret_cast<float *>(smem_raw);
     float *xs = reinterpret_cast<float *>(smem_raw + a.tab_bytes); // [NR][lds_floats]
@@ -2352,19 +2356,40 @@ __global__ __launch_bounds__(kTileOut) void pv_resample_kernel(const ResArgs a) 
     const int nr = a.rows - row0 < NR ? a.rows - row0 : NR;
     uint2 oe = make_uint2(0u, 0u);
     if (tid < tile.kcnt) oe = a.otab[(int64_t)blockIdx.x * kTileOut + tid];
+    // the tile's stream samples of every row, all loads in flight before the first LDS write (a tile needs at most
+    // two samples per thread and row at the ratios that resample: n_cnt <= 256 * num/den + filt_len)
+    float xv[NR][2];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const float *__restrict__ st = a.stream + (int64_t)(r < nr ? row0 + r : row0) * ((int64_t)a.smask + 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = tid + h * kTileOut;
+            const int64_t n = tile.n_lo + i; // the stream is zero before its first sample (skip_zeros, :1225)
+            xv[r][h] = (i < tile.n_cnt && n >= 0) ? st[(uint32_t)n & (uint32_t)a.smask] : 0.f;
+        }
+    }
     if (kRes == 2) {
         const int cnt = a.oversample * (NF + 1);
         for (int i = tid; i < cnt; i += nt) tab4[i] = a.tab4[i];
     } else {
         for (int i = tid; i < a.sinc_len; i += nt) stab[i] = a.sinc[i];
     }
-    for (int r = 0; r < nr; ++r) {
-        const float *__restrict__ st = a.stream + (int64_t)(row0 + r) * ((int64_t)a.smask + 1);
-        for (int i = tid; i < tile.n_cnt; i += nt) {
-            const int64_t n = tile.n_lo + i; // the stream is zero before its first sample (skip_zeros, :1225)
-            xs[r * a.lds_floats + i] = n >= 0 ? st[(uint32_t)n & (uint32_t)a.smask] : 0.f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = tid + h * kTileOut;
+            if (i < tile.n_cnt) xs[r * a.lds_floats + i] = xv[r][h];
         }
     }
+    // (longer tiles -- strong down-sampling, more than two samples per thread -- take the rest in a loop)
+    for (int i = tid + 2 * kTileOut; i < tile.n_cnt; i += nt)
+        for (int r = 0; r < nr; ++r) {
+            const int64_t n = tile.n_lo + i;
+            const float *__restrict__ st = a.stream + (int64_t)(row0 + r) * ((int64_t)a.smask + 1);
+            xs[r * a.lds_floats + i] = n >= 0 ? st[(uint32_t)n & (uint32_t)a.smask] : 0.f;
+        }
     __syncthreads();
     if (tid >= tile.kcnt) return;
     float *__restrict__ out = a.out + (int64_t)row0 * a.out_stride_row + (tile.k0 - a.k_base) + tid;
@@ -2381,8 +2406,8 @@ __global__ __launch_bounds__(kTileOut) void pv_resample_kernel(const ResArgs a) 
             const v2f c01 = {c.x, c.y}, c23 = {c.z, c.w};
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                const float xv = x[r * a.lds_floats + j]; // a missing second row reads stale LDS: never stored
-                const v2f xx = {xv, xv};
+                const float xr = x[r * a.lds_floats + j]; // a missing row holds zeros: computed, never stored
+                const v2f xx = {xr, xr};
                 a01[r] += xx * c01;
                 a23[r] += xx * c23;
             }
@@ -2408,8 +2433,8 @@ __global__ __launch_bounds__(kTileOut) void pv_resample_kernel(const ResArgs a) 
 
 void launch_resample(const ResArgs &a, hipStream_t st) {
     if (a.ntiles <= 0) return;
-    const size_t lds = (size_t)a.tab_bytes + sizeof(float) * (size_t)a.lds_floats * 2;
-    const dim3 grid(a.ntiles, (a.rows + 1) / 2);
+    const size_t lds = (size_t)a.tab_bytes + sizeof(float) * (size_t)a.lds_floats * kResRows;
+    const dim3 grid(a.ntiles, (a.rows + kResRows - 1) / kResRows);
     static unsigned long long m1 = 0, m2 = 0;
     if (a.interp) {
         allow_big_lds_dev(pv_resample_kernel<2>, m2);
