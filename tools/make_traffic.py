@@ -23,6 +23,10 @@ def canonical(k):
         return "pv_synth_kernel"
     if k.startswith("pv_ola_kernel"):  # pv_ola_kernel<resampling mode>
         return "pv_ola_kernel"
+    if k.startswith("pv_synth_chain_kernel"):  # fused synthesis + overlap-add
+        return "pv_synth_ola_kernel"
+    if k.startswith("pv_resample_kernel") or k.startswith("pv_frames_chain_kernel"):
+        return "pv_ola_kernel"  # the fused path's second kernel, reported under the overlap-add stage's name
     return k
 
 
