@@ -23,27 +23,24 @@
 PV_AT_HD uint32_t pv_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 PV_AT_HD float pv_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-// (written without branches or indexed constant tables: on the device a lane-dependent table index would put the
-// tables in scratch memory, and the four argument reductions would run one after the other under divergence; here
-// each candidate numerator / denominator is formed with the reference's own operations and ONE division serves
-// whichever interval the lane is in -- x / 1 is x exactly, for the interval that is not reduced)
-PV_AT_HD float pv_atanf_fd(float x) {
-    const int32_t hx = (int32_t)pv_f2u(x);
-    const int32_t ix = hx & 0x7fffffff;
-    if (ix >= 0x4c000000) { // |x| >= 2^25 (or NaN)
-        if (ix > 0x7f800000) return x + x;
-        const float r = 1.5707962513e+00f + 7.5497894159e-08f;
-        return hx > 0 ? r : -1.5707962513e+00f - 7.5497894159e-08f;
-    }
-    if (ix < 0x31000000) return x; // |x| < 2^-29
-    const float ax = pv_u2f((uint32_t)ix);
-    // id: -1 |x| < 7/16 (no reduction), 0 < 11/16, 1 < 19/16, 2 < 39/16, 3 otherwise
+// Written as one straight line of code with selects: no branches, no indexed constant tables.  On the device a
+// lane-dependent table index would put the tables in scratch memory, and the reference's early returns would run
+// one after the other under divergence (a first, literal version cost 219 vector instructions and three divisions
+// per call; this one 2 divisions).  Each candidate numerator / denominator of the argument reduction is formed with
+// the reference's own operations and ONE division serves whichever interval the lane is in (x / 1 is x exactly, for
+// the interval that is not reduced); the special cases of e_atan2f.c overwrite the general result at the end, in
+// the reference's order of precedence.  Its x == 1 shortcut (atanf(y)) gives what the general path gives and is
+// dropped.
+
+// atanf for a non-negative argument (|y / x|): s_atanf.c without the sign handling
+PV_AT_HD float pv_atanf_pos_fd(const float q) {
+    const int32_t ix = (int32_t)pv_f2u(q); // q >= 0 or NaN: the sign bit is clear
     const bool r0 = ix >= 0x3ee00000, r1 = ix >= 0x3f300000, r2 = ix >= 0x3f980000, r3 = ix >= 0x401c0000;
-    float num = x, den = 1.0f, hi = 0.f, lo = 0.f;
-    if (r0) num = 2.0f * ax - 1.0f, den = 2.0f + ax, hi = 4.6364760399e-01f, lo = 5.0121582440e-09f;
-    if (r1) num = ax - 1.0f, den = ax + 1.0f, hi = 7.8539812565e-01f, lo = 3.7748947079e-08f;
-    if (r2) num = ax - 1.5f, den = 1.0f + 1.5f * ax, hi = 9.8279368877e-01f, lo = 3.4473217170e-08f;
-    if (r3) num = -1.0f, den = ax, hi = 1.5707962513e+00f, lo = 7.5497894159e-08f;
+    float num = q, den = 1.0f, hi = 0.f, lo = 0.f;
+    if (r0) num = 2.0f * q - 1.0f, den = 2.0f + q, hi = 4.6364760399e-01f, lo = 5.0121582440e-09f;
+    if (r1) num = q - 1.0f, den = q + 1.0f, hi = 7.8539812565e-01f, lo = 3.7748947079e-08f;
+    if (r2) num = q - 1.5f, den = 1.0f + 1.5f * q, hi = 9.8279368877e-01f, lo = 3.4473217170e-08f;
+    if (r3) num = -1.0f, den = q, hi = 1.5707962513e+00f, lo = 7.5497894159e-08f;
     const float t = num / den;
     const float z = t * t;
     const float w = z * z;
@@ -51,50 +48,58 @@ PV_AT_HD float pv_atanf_fd(float x) {
                           w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
     const float s2 = w * (-2.0000000298e-01f + w * (-1.1111110449e-01f + w * (-7.6918758452e-02f +
                           w * (-5.8335702866e-02f + w * -3.6531571299e-02f))));
-    if (!r0) return t - t * (s1 + s2);
-    const float r = hi - ((t * (s1 + s2) - lo) - t);
-    return hx < 0 ? -r : r;
+    const float reduced = hi - ((t * (s1 + s2) - lo) - t);
+    float r = r0 ? reduced : t - t * (s1 + s2);
+    if (ix < 0x31000000) r = q;                                              // |x| < 2^-29
+    if (ix >= 0x4c000000) r = 1.5707962513e+00f + 7.5497894159e-08f;         // |x| >= 2^25
+    if (ix > 0x7f800000) r = q + q;                                          // NaN
+    return r;
 }
 
-PV_AT_HD float pv_atan2f_fd(float y, float x) {
+// The same for FINITE y and x (what a transform of finite samples produces): the infinity / NaN cases of the
+// reference cannot occur and are left out; zeros, signed zeros and out-of-range quotients are handled as above.
+PV_AT_HD float pv_atan2f_fd_finite(const float y, const float x) {
+    const float tiny = 1.0e-30f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int32_t hx = (int32_t)pv_f2u(x), hy = (int32_t)pv_f2u(y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    const int32_t k = (iy - ix) >> 23;
+    float z = pv_atanf_pos_fd(pv_u2f(pv_f2u(y / x) & 0x7fffffffu)); // (y / x = inf or NaN when x = 0: overwritten below)
+    if (hx < 0 && k < -60) z = 0.0f;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    const float zq = z - pi_lo;
+    float r = hx < 0 ? pi - zq : z;                              // atan(+, -) : atan(+, +)
+    if (ix == 0) r = pi_o_2 + tiny;                              // x = 0
+    if (iy == 0) r = hx < 0 ? pi + tiny : 0.0f;                  // y = 0: +-0 for x >= 0, +-pi for x < 0
+    return pv_u2f(pv_f2u(r) | ((uint32_t)hy & 0x80000000u));    // the result takes y's sign: atan(-, .) = -atan(+, .)
+}
+
+PV_AT_HD float pv_atan2f_fd(const float y, const float x) {
     const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f,
                 pi_lo = -8.7422776573e-08f;
     const int32_t hx = (int32_t)pv_f2u(x), hy = (int32_t)pv_f2u(y);
     const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
-    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y; // NaN
-    if (hx == 0x3f800000) return pv_atanf_fd(y);          // x = 1.0
-    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);    // 2 * sign(x) + sign(y)
-    if (iy == 0) { // y = 0
-        if (m < 2) return y;
-        return m == 2 ? pi + tiny : -pi - tiny;
-    }
-    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny; // x = 0
-    if (ix == 0x7f800000) { // x = inf
-        if (iy == 0x7f800000) {
-            switch (m) {
-            case 0: return pi_o_4 + tiny;
-            case 1: return -pi_o_4 - tiny;
-            case 2: return 3.0f * pi_o_4 + tiny;
-            default: return -3.0f * pi_o_4 - tiny;
-            }
-        }
-        switch (m) {
-        case 0: return 0.0f;
-        case 1: return -0.0f;
-        case 2: return pi + tiny;
-        default: return -pi - tiny;
-        }
-    }
-    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny; // y = inf
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2); // 2 * sign(x) + sign(y)
+    // general case: atan(|y / x|), then the quadrant
     const int32_t k = (iy - ix) >> 23;
-    float z;
-    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;      // |y / x| > 2^60
-    else if (hx < 0 && k < -60) z = 0.0f;        // |y| / x < -2^60
-    else z = pv_atanf_fd(pv_u2f(pv_f2u(y / x) & 0x7fffffffu));
-    switch (m) {
-    case 0: return z;
-    case 1: return pv_u2f(pv_f2u(z) ^ 0x80000000u);
-    case 2: return pi - (z - pi_lo);
-    default: return (z - pi_lo) - pi;
+    float z = pv_atanf_pos_fd(pv_u2f(pv_f2u(y / x) & 0x7fffffffu));
+    if (hx < 0 && k < -60) z = 0.0f;              // |y| / x < -2^60
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;       // |y / x| > 2^60
+    const float zq = z - pi_lo;
+    float r = z;                                                          // atan(+, +)
+    if (m == 1) r = pv_u2f(pv_f2u(z) ^ 0x80000000u);                      // atan(-, +)
+    if (m == 2) r = pi - zq;                                              // atan(+, -)
+    if (m == 3) r = zq - pi;                                              // atan(-, -)
+    // special values, later lines taking precedence as the reference's earlier tests do
+    const bool ypos = hy >= 0;
+    if (iy == 0x7f800000) r = ypos ? pi_o_2 + tiny : -pi_o_2 - tiny;      // y = inf
+    if (ix == 0x7f800000) {                                               // x = inf
+        const float qinf = hx >= 0 ? pi_o_4 + tiny : 3.0f * pi_o_4 + tiny; // ... and y = inf
+        const float fin = hx >= 0 ? 0.0f : pi + tiny;
+        const float a = iy == 0x7f800000 ? qinf : fin;
+        r = ypos ? a : -a;
     }
+    if (ix == 0) r = ypos ? pi_o_2 + tiny : -pi_o_2 - tiny;               // x = 0
+    if (iy == 0) r = m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);       // y = 0
+    if (ix > 0x7f800000 || iy > 0x7f800000) r = x + y;                    // NaN
+    return r;
 }

@@ -214,6 +214,7 @@ struct Core {
     // their images are carried here between launches.  On by default (AUDIOMOD_PV_FUSED=0 selects the frame ring +
     // tile kernel instead, which cannot represent dropped slices).
     bool use_chain = false;
+    bool three_stage = false; // pipelined batch path: resampling of chunk i-2 between the front of i and the fused kernel of i-1
     int chain_AR = 0, chain_smask = 0, chain_waves = 0;
     int chain_max_adv = 0; // set before init(): the largest overlap-add advance the planner can emit
     DevBuf<float> st_acc, stream; // accumulator-ring images; normalised overlap-add stream rings (resampling only)
@@ -320,7 +321,11 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
         // (beside the rotation chain's kernel -- the pipelined batch path -- twelve: its six-wave workgroups then
         // find a CU's fourth wave slot and 8 KB of LDS free and run at their stand-alone speed; with fourteen or
         // sixteen they wait for a fused workgroup to finish and the overlap is gone: 54.1 vs 58.6 ms per step)
-        int wmax = d.fft.nc == 2048 ? 8 : (pipelined_planes ? 12 : 16);
+        {
+            const char *e3 = getenv("AUDIOMOD_PV_THREE_STAGE");
+            three_stage = pipelined_planes && d.resample && !(e3 && atoi(e3) == 0);
+        }
+        int wmax = d.fft.nc == 2048 ? 8 : ((pipelined_planes && !three_stage) ? 12 : 16);
         if (const char *e = getenv("AUDIOMOD_PV_CHAIN_WAVES")) { // tuning knob: upper bound of waves per workgroup
             const int v = atoi(e);
             if (v >= 1 && v < wmax) wmax = v;
@@ -623,6 +628,10 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
                         const InAddr *carrier, float *out, int64_t out_stride_row, int64_t k_base,
                         hipStream_t st, hipEvent_t *ev, int part, hipStream_t st_chain, hipEvent_t ev_match,
                         hipEvent_t ev_chain, bool single_launch, const ChainLaunch *chain) const {
+    // part 3 / 4: the back of a chunk in two pieces (fused path: 3 = everything up to the fused synthesis +
+    // overlap-add kernel, 4 = the resampling kernel), for the three-stage order of pv_batch_run
+    const bool only_resample = part == 4, no_resample = part == 3;
+    if (part == 3 || part == 4) part = 2;
     const bool front = part != 2, back = part != 1;
     StreamArgs fused{};
     const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder;
@@ -641,7 +650,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
             if (ev) (void)hipEventRecord(ev[2 * k + 1], st_chain);
             (void)hipEventRecord(ev_chain, st_chain);
         } else if (part == 2) {
-            (void)hipStreamWaitEvent(st, ev_chain, 0);
+            if (!only_resample) (void)hipStreamWaitEvent(st, ev_chain, 0);
         } else {
             rec(2 * k);
             launch_on(st);
@@ -783,7 +792,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     sa.rot = rot.p;
     sa.frames = frames.p;
     sa.FR = FR;
-    if (d.cepstral) {
+    if (d.cepstral && !only_resample) {
         CepstralArgs ca{};
         ca.tb = tb;
         ca.Tn = Tn;
@@ -846,9 +855,10 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ra.out = out;
         ra.out_stride_row = out_stride_row;
         ra.k_base = k_base;
-        if (d.resample && chain->res_stream && chain->ev_ring_free)
+        if (d.resample && chain->res_stream && chain->ev_ring_free && !only_resample)
             (void)hipStreamWaitEvent(st, chain->ev_ring_free, 0);
-        if (wave_fft()) {
+        if (only_resample) {
+        } else if (wave_fft()) {
             // synthesis and overlap-add in one kernel: the frames stay in LDS
             rec(2 * PV_K_SYNTH_OLA);
             launch_synth_chain(sa, ca, st);
@@ -859,8 +869,9 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
             rec(2 * PV_K_SYNTH + 1);
             rec(2 * PV_K_OLA_RESAMPLE);
             launch_frames_chain(ca, st);
-            if (!d.resample) rec(2 * PV_K_OLA_RESAMPLE + 1);
+            if (!d.resample || no_resample) rec(2 * PV_K_OLA_RESAMPLE + 1);
         }
+        if (no_resample) return;
         if (d.resample && chain->res_stream) {
             (void)hipEventRecord(chain->ev_fused, st);
             (void)hipStreamWaitEvent(chain->res_stream, chain->ev_fused, 0);
@@ -869,7 +880,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
             if (ev) (void)hipEventRecord(ev[2 * PV_K_OLA_RESAMPLE + 1], chain->res_stream);
             (void)hipEventRecord(chain->ev_res, chain->res_stream);
         } else if (d.resample) {
-            if (wave_fft()) rec(2 * PV_K_OLA_RESAMPLE);
+            if (wave_fft() || only_resample) rec(2 * PV_K_OLA_RESAMPLE);
             launch_resample(ra, st);
             rec(2 * PV_K_OLA_RESAMPLE + 1);
         }
@@ -1309,14 +1320,28 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
     const size_t nchunks = b->chunks.size();
     if (piped) {
         // the chain stream must not start before the caller's stream has reached this run (state reset, inputs)
-        hipEvent_t *prev_ev = nullptr;
+        // Fused path with a resampling kernel: three stages -- front of chunk i, resampling of chunk i-2, fused
+        // kernel of chunk i-1 -- so that the rotation chain of chunk i (started behind its match kernel) runs
+        // beside the resampling kernel, whose workgroups leave it room on every CU, and is done when the fused
+        // kernel, which fills the CUs' LDS, starts.
+        const bool three = c.use_chain && c.d.resample && c.wave_fft() && b->res_stream == nullptr && c.three_stage;
+        std::vector<hipEvent_t *> evs(nchunks, nullptr);
         for (size_t ci = 0; ci < nchunks; ++ci) {
-            hipEvent_t *ev = events_for(ci);
-            launch(ci, ev, 1);
-            if (ci > 0) launch(ci - 1, prev_ev, 2);
-            prev_ev = ev;
+            evs[ci] = events_for(ci);
+            launch(ci, evs[ci], 1);
+            if (three) {
+                if (ci > 1) launch(ci - 2, evs[ci - 2], 4);
+                if (ci > 0) launch(ci - 1, evs[ci - 1], 3);
+            } else if (ci > 0) {
+                launch(ci - 1, evs[ci - 1], 2);
+            }
         }
-        if (nchunks > 0) launch(nchunks - 1, prev_ev, 2);
+        if (three) {
+            if (nchunks > 1) launch(nchunks - 2, evs[nchunks - 2], 4);
+            if (nchunks > 0) launch(nchunks - 1, evs[nchunks - 1], 3), launch(nchunks - 1, evs[nchunks - 1], 4);
+        } else if (nchunks > 0) {
+            launch(nchunks - 1, evs[nchunks - 1], 2);
+        }
     } else {
         for (size_t ci = 0; ci < nchunks; ++ci) launch(ci, events_for(ci), 0);
     }

@@ -198,10 +198,10 @@ __global__ __launch_bounds__(kFftThreads) void pv_analyze_kernel(const AnalyzeAr
             const float m0 = sqrtf(r0 * r0 + 0.f * 0.f), mn = sqrtf(rn * rn + 0.f * 0.f);
             mag[0] = m0;
             smag[0] = m0;
-            ph[0] = pv_atan2f_fd(0.f, r0);
+            ph[0] = pv_atan2f_fd_finite(0.f, r0);
             mag[nc] = mn;
             smag[nc] = mn;
-            ph[nc] = pv_atan2f_fd(0.f, rn);
+            ph[nc] = pv_atan2f_fd_finite(0.f, rn);
         } else {
             const float2 fpk = buf[k];
             const float2 q = buf[nc - k];
@@ -215,12 +215,12 @@ __global__ __launch_bounds__(kFftThreads) void pv_analyze_kernel(const AnalyzeAr
                 const float m = sqrtf(xr * xr + xi * xi);
                 mag[k] = m;
                 smag[k] = m;
-                ph[k] = pv_atan2f_fd(xi, xr);
+                ph[k] = pv_atan2f_fd_finite(xi, xr);
             }
             const float m2 = sqrtf(yr * yr + yi * yi);
             mag[nc - k] = m2;
             smag[nc - k] = m2;
-            ph[nc - k] = pv_atan2f_fd(yi, yr);
+            ph[nc - k] = pv_atan2f_fd_finite(yi, yr);
         }
     }
     if (!a.find_peaks) return;
@@ -383,8 +383,8 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
             const float r0 = tdc.x + tdc.y, rn = tdc.x - tdc.y;
             mlo[0] = sqrtf(r0 * r0 + 0.f * 0.f);
             mhi[0] = sqrtf(rn * rn + 0.f * 0.f);
-            plo[0] = pv_atan2f_fd(0.f, r0);
-            phi[0] = pv_atan2f_fd(0.f, rn);
+            plo[0] = pv_atan2f_fd_finite(0.f, r0);
+            phi[0] = pv_atan2f_fd_finite(0.f, rn);
         } else {
             const cf fpk = lds[W::pad(k)];
             const cf q = lds[W::pad(NC - k)];
@@ -396,8 +396,8 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
             const float yr = (f1k.x - tq.x) * 0.5f, yi = (tq.y - f1k.y) * 0.5f;
             mlo[j] = sqrtf(xr * xr + xi * xi);
             mhi[j] = sqrtf(yr * yr + yi * yi);
-            plo[j] = pv_atan2f_fd(xi, xr);
-            phi[j] = pv_atan2f_fd(yi, yr);
+            plo[j] = pv_atan2f_fd_finite(xi, xr);
+            phi[j] = pv_atan2f_fd_finite(yi, yr);
         }
     }
     float mmid = 0.f, pmid = 0.f;
@@ -409,7 +409,7 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
         const cf tq = wf_cmul(f2k, swmid);
         const float yr = (f1k.x - tq.x) * 0.5f, yi = (tq.y - f1k.y) * 0.5f;
         mmid = sqrtf(yr * yr + yi * yi);
-        pmid = pv_atan2f_fd(yi, yr);
+        pmid = pv_atan2f_fd_finite(yi, yr);
     }
     // Out through the (now free) wave-private LDS region: a lane holds bins k and NC - k, the planes want runs of
     // consecutive bins, and stores are issue-bound -- four 16-byte stores per lane and plane instead of sixteen

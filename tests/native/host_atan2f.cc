@@ -15,6 +15,13 @@ int main(int argc, char **argv) {
     auto check = [&](float y, float x) {
         const float a = pv_atan2f_fd(y, x), b = atan2f(y, x);
         ++n;
+        if (std::isfinite(y) && std::isfinite(x)) { // the variant the kernels use: finite arguments only
+            const float c = pv_atan2f_fd_finite(y, x);
+            if (pv_f2u(c) != pv_f2u(b)) {
+                if (bad < 10) printf("MISMATCH (finite variant) y=%a x=%a got=%a want=%a\n", y, x, c, b);
+                ++bad;
+            }
+        }
         if (pv_f2u(a) != pv_f2u(b) && !(a != a && b != b)) {
             if (bad < 10) printf("MISMATCH y=%a x=%a got=%a want=%a\n", y, x, a, b);
             ++bad;

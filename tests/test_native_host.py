@@ -63,4 +63,4 @@ def test_atan2f_restatement_is_bit_identical_to_libm(tmp_path):
             pytest.skip("glibc >= 2.41 computes atan2f differently (correctly rounded): not the reference build's libm")
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
     dev = open(os.path.join(ROOT, "audiomod_amd/csrc/pv_kernels.hip")).read()
-    assert "pv_atan2f_fd(" in dev and " atan2f(" not in dev
+    assert "pv_atan2f_fd_finite(" in dev and " atan2f(" not in dev
