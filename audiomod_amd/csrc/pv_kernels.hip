@@ -374,17 +374,19 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
     const int64_t plane = ((int64_t)row * a.TR + slot);
     float *__restrict__ mag = a.mag + plane * tb.HP;
     float *__restrict__ ph = a.phase + plane * tb.HP;
-    float mlo[J], mhi[J], plo[J], phi[J];
+    // The split's output bins, cartesian, go back to the wave's LDS region in natural order; the polar conversion
+    // then runs as a ROLLED loop over runs of four consecutive bins.  (Unrolled over a lane's 2 J bins it was 2 J
+    // inlined copies of atan2f -- libm's algorithm, pv_atan2f.h, ~100 instructions each -- and the 4096-point kernel
+    // ran 2.3x slower than with the device library's shorter atan2f; a run of four per iteration keeps four
+    // independent evaluations in flight and the phases / magnitudes leave as 16-byte stores.)
+    cf xlo[J], xhi[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int k = lane + 64 * j;
         if (j == 0 && lane == 0) {
             const cf tdc = lds[W::pad(0)];
-            const float r0 = tdc.x + tdc.y, rn = tdc.x - tdc.y;
-            mlo[0] = sqrtf(r0 * r0 + 0.f * 0.f);
-            mhi[0] = sqrtf(rn * rn + 0.f * 0.f);
-            plo[0] = pv_atan2f_fd_finite(0.f, r0);
-            phi[0] = pv_atan2f_fd_finite(0.f, rn);
+            xlo[0] = cf{tdc.x + tdc.y, 0.f}; // DC and Nyquist: imaginary part forced to 0 (kiss_fftr.c:97-102)
+            xhi[0] = cf{tdc.x - tdc.y, 0.f};
         } else {
             const cf fpk = lds[W::pad(k)];
             const cf q = lds[W::pad(NC - k)];
@@ -392,53 +394,63 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
             const cf f1k = wf_add(fpk, fpnk);
             const cf f2k = wf_sub(fpk, fpnk);
             const cf tq = wf_cmul(f2k, sw[j]);
-            const float xr = (f1k.x + tq.x) * 0.5f, xi = (f1k.y + tq.y) * 0.5f;
-            const float yr = (f1k.x - tq.x) * 0.5f, yi = (tq.y - f1k.y) * 0.5f;
-            mlo[j] = sqrtf(xr * xr + xi * xi);
-            mhi[j] = sqrtf(yr * yr + yi * yi);
-            plo[j] = pv_atan2f_fd_finite(xi, xr);
-            phi[j] = pv_atan2f_fd_finite(yi, yr);
+            xlo[j] = cf{(f1k.x + tq.x) * 0.5f, (f1k.y + tq.y) * 0.5f};
+            xhi[j] = cf{(f1k.x - tq.x) * 0.5f, (tq.y - f1k.y) * 0.5f};
         }
     }
-    float mmid = 0.f, pmid = 0.f;
+    cf xmid = cf{0.f, 0.f};
     if (lane == 0) { // k == NC/2 pairs with itself: the second assignment of the reference loop wins
         const cf fpk = lds[W::pad(NC / 2)];
         const cf fpnk = cf{fpk.x, -fpk.y};
         const cf f1k = wf_add(fpk, fpnk);
         const cf f2k = wf_sub(fpk, fpnk);
         const cf tq = wf_cmul(f2k, swmid);
-        const float yr = (f1k.x - tq.x) * 0.5f, yi = (tq.y - f1k.y) * 0.5f;
-        mmid = sqrtf(yr * yr + yi * yi);
-        pmid = pv_atan2f_fd_finite(yi, yr);
+        xmid = cf{(f1k.x - tq.x) * 0.5f, (tq.y - f1k.y) * 0.5f};
     }
-    // Out through the (now free) wave-private LDS region: a lane holds bins k and NC - k, the planes want runs of
-    // consecutive bins, and stores are issue-bound -- four 16-byte stores per lane and plane instead of sixteen
-    // 4-byte ones.  Phases first, magnitudes second: the magnitudes stay in LDS for the peak search.
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = lane + 64 * j;
+        if (j == 0 && lane == 0) {
+            lds[0] = xlo[0];
+            lds[NC] = xhi[0];
+        } else {
+            lds[k] = xlo[j];
+            lds[NC - k] = xhi[j];
+        }
+    }
+    if (lane == 0) lds[NC / 2] = xmid;
+    wave_sync();
+    // polar (FFT.cc:2623-2630): mag = sqrtf(re^2 + im^2), phase = atan2f(im, re).  The magnitudes also stay in LDS
+    // for the peak search: a run's four floats land on the first half of the 32 bytes its cartesian values
+    // occupied, and every later run lies beyond them.
     float *smag = reinterpret_cast<float *>(lds);
-    auto plane_out = [&](const float (&lo)[J], const float (&hi)[J], float mid, float *__restrict__ dst) {
-        wave_sync();
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const int k = lane + 64 * j;
-            if (j == 0 && lane == 0) {
-                smag[0] = lo[0];
-                smag[NC] = hi[0];
-            } else {
-                smag[k] = lo[j];
-                smag[NC - k] = hi[j];
-            }
-        }
-        if (lane == 0) smag[NC / 2] = mid;
-        wave_sync();
-#pragma unroll
-        for (int q = 0; q < NC / 256; ++q) {
-            const int i4 = 4 * (lane + 64 * q);
-            *reinterpret_cast<float4 *>(dst + i4) = *reinterpret_cast<const float4 *>(smag + i4);
-        }
-        if (lane == 0) dst[NC] = hi[0];
-    };
-    plane_out(plo, phi, pmid, ph);
-    plane_out(mlo, mhi, mmid, mag);
+    const cf xnyq = lds[NC];
+#pragma nounroll
+    for (int q = 0; q < NC / 256; ++q) {
+        const int i4 = 4 * (lane + 64 * q);
+        const float4 c01 = *reinterpret_cast<const float4 *>(lds + i4);     // bins i4, i4 + 1
+        const float4 c23 = *reinterpret_cast<const float4 *>(lds + i4 + 2); // bins i4 + 2, i4 + 3
+        float4 m4, p4;
+        m4.x = sqrtf(c01.x * c01.x + c01.y * c01.y);
+        m4.y = sqrtf(c01.z * c01.z + c01.w * c01.w);
+        m4.z = sqrtf(c23.x * c23.x + c23.y * c23.y);
+        m4.w = sqrtf(c23.z * c23.z + c23.w * c23.w);
+        p4.x = pv_atan2f_fd_finite(c01.y, c01.x);
+        p4.y = pv_atan2f_fd_finite(c01.w, c01.z);
+        p4.z = pv_atan2f_fd_finite(c23.y, c23.x);
+        p4.w = pv_atan2f_fd_finite(c23.w, c23.z);
+        *reinterpret_cast<float4 *>(ph + i4) = p4;
+        *reinterpret_cast<float4 *>(mag + i4) = m4;
+        *reinterpret_cast<float4 *>(smag + i4) = m4;
+    }
+    if (lane == 0) {
+        const float mn = sqrtf(xnyq.x * xnyq.x + xnyq.y * xnyq.y);
+        ph[NC] = pv_atan2f_fd_finite(xnyq.y, xnyq.x);
+        mag[NC] = mn;
+        smag[NC] = mn;
+    }
+    wave_sync();
     if (!a.find_peaks) return;
     // ordered list first into LDS (behind the magnitudes), then out in whole 32-bit words: three coalesced
     // stores per lane instead of one sparsely populated 16-bit store per group of 64 bins
