@@ -10,7 +10,7 @@ ARCH  := gfx950
 # instructions they replace (measured: analysis kernel -11 %, synthesis -3 %, overlap-add -5 % with the flag);
 # the one loop that gains from packed math (the resampler's) asks for it explicitly.  Same arithmetic either way.
 CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Iinclude -Iaudiomod_amd/csrc -Wall -Wno-unused-result
-SRC := audiomod_amd/csrc/pv_kernels.hip audiomod_amd/csrc/pv_engine.cc audiomod_amd/csrc/pv_plan.cc audiomod_amd/csrc/phasevocoder.cc
+SRC := audiomod_amd/csrc/pv_kernels.hip audiomod_amd/csrc/pv_hostio.hip audiomod_amd/csrc/pv_engine.cc audiomod_amd/csrc/pv_plan.cc audiomod_amd/csrc/phasevocoder.cc
 HDR := $(wildcard audiomod_amd/csrc/*.h) $(wildcard include/*.h) $(wildcard include/dafx/*.h)
 LIB := audiomod_amd/lib/libaudiomod_pv.so
 

@@ -214,6 +214,12 @@ struct Core {
     // their images are carried here between launches.  On by default (AUDIOMOD_PV_FUSED=0 selects the frame ring +
     // tile kernel instead, which cannot represent dropped slices).
     bool use_chain = false;
+    // The fused kernel runs one workgroup per row: below ~3/4 of the chip's 256 CUs in rows it leaves CUs idle and the
+    // tile path (frames through HBM, thousands of small workgroups) is faster.  A batch takes the fused path when it
+    // has the rows, or when its plan contains dropped slices (only the fused path's accumulator can represent
+    // them); the streaming engine always does (it must follow whatever the caller's call sizes lead to).
+    bool chain_required = false; // set before init()
+    static constexpr int kChainMinRows = 192;
     bool three_stage = false; // pipelined batch path: resampling of chunk i-2 between the front of i and the fused kernel of i-1
     int chain_AR = 0, chain_smask = 0, chain_waves = 0;
     int chain_max_adv = 0; // set before init(): the largest overlap-add advance the planner can emit
@@ -302,7 +308,12 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     otab_off = (ola_lds_floats + 3) & ~3;
     wacc_pitch = otab_off + 2 * kTileOut;
     lookback = (d.N + tile_span) / d.min_shift + 3;
-    use_chain = chain_wanted();
+    use_chain = chain_wanted() && (chain_required || rows >= kChainMinRows);
+    if (const char *e = getenv("AUDIOMOD_PV_FUSED")) // =2: the fused path whatever the row count
+        if (atoi(e) == 2) use_chain = true;
+    if (!use_chain && (tile_span + d.N) / d.min_shift + 3 > kMaxTileFrames) {
+        if (chain_wanted()) use_chain = true; // the tile path cannot hold that many frames per tile: fused after all
+    }
     if (!use_chain && (tile_span + d.N) / d.min_shift + 3 > kMaxTileFrames) {
         g_last_error = "hop too small relative to the FFT size for the OLA tile";
         return PV_ERR_UNSUPPORTED;
@@ -1114,8 +1125,13 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
         if ((st = derive(*cfg, dd)) != PV_OK) return st;
         if ((st = plan_batch(dd, frames, block, flush != 0, b->plan)) != PV_OK) return st;
         int mx = 1;
-        for (const SliceRec &r : b->plan.slices) mx = r.adv > mx ? r.adv : mx;
+        bool drops = false;
+        for (const SliceRec &r : b->plan.slices) {
+            mx = r.adv > mx ? r.adv : mx;
+            drops = drops || r.adv == 0;
+        }
         b->core.chain_max_adv = mx;
+        b->core.chain_required = drops;
     }
     st = b->core.init(*cfg, device, nstreams, Tc);
     if (st != PV_OK) return st;
@@ -1396,6 +1412,7 @@ int pv_create(const pv_config *cfg, int device, pv_engine **out) {
     if (!cfg || !out) return PV_ERR_INVALID_ARG;
     *out = nullptr;
     std::unique_ptr<pv_engine> e(new pv_engine());
+    e->core.chain_required = true;
     int st = e->core.init(*cfg, device, 1, kStreamChunk);
     if (st != PV_OK) return st;
     Core &c = e->core;

@@ -101,6 +101,15 @@ def lib():
     L.pv_batch_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pv_batch_enable_timing.argtypes = [C.c_void_p, C.c_int]
     L.pv_batch_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pv_hostio_create.argtypes = [C.POINTER(Config), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int, C.c_int32,
+                                   C.c_int32, C.POINTER(C.c_void_p)]
+    L.pv_hostio_destroy.argtypes = [C.c_void_p]
+    L.pv_hostio_out_frames.argtypes = [C.c_void_p]
+    L.pv_hostio_out_frames.restype = C.c_int64
+    L.pv_hostio_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pv_host_alloc.argtypes = [C.c_size_t]
+    L.pv_host_alloc.restype = C.c_void_p
+    L.pv_host_free.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -321,3 +330,52 @@ class Batch:
         n = (C.c_int64 * len(KERNELS))()
         _check(self.L.pv_batch_kernel_times(self.h, ms, n), "pv_batch_kernel_times")
         return {KERNELS[k]: (ms[k], n[k]) for k in range(len(KERNELS))}
+
+
+class HostIO:
+    """nstreams independent streams whose input and output live in HOST memory (what the reference's callers hold:
+    main/main.cc:152-162,484-491), float32 or int16 on the wire; groups of streams are staged through the GPU with
+    copy-in, kernels and copy-out overlapped (include/audiomod_pv.h pv_hostio_*)."""
+
+    def __init__(self, nstreams, frames, channels=2, block=480, flush=True, device=0, streams_per_group=16,
+                 wire="f32", **kw):
+        self.L = lib()
+        self.cfg = make_config(channels, **kw)
+        self.nstreams, self.frames, self.channels = nstreams, frames, channels
+        self.wire = {"f32": 0, "i16": 1}[wire]
+        self.dtype = np.float32 if self.wire == 0 else np.int16
+        self.h = C.c_void_p()
+        _check(self.L.pv_hostio_create(C.byref(self.cfg), nstreams, frames, block, 1 if flush else 0, device,
+                                       streams_per_group, self.wire, C.byref(self.h)), "pv_hostio_create")
+        self.out_frames = self.L.pv_hostio_out_frames(self.h)
+        self._pinned = []
+
+    def pinned(self, shape):
+        """numpy array of this job's wire type in page-locked host memory (freed with the object)"""
+        n = int(np.prod(shape)) * np.dtype(self.dtype).itemsize
+        p = self.L.pv_host_alloc(max(n, 1))
+        if not p:
+            raise PvError("pv_host_alloc failed")
+        self._pinned.append(p)
+        buf = (C.c_char * max(n, 1)).from_address(p)
+        return np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def run(self, host_in, host_out=None):
+        assert host_in.dtype == self.dtype and host_in.flags.c_contiguous
+        assert tuple(host_in.shape) == (self.nstreams, self.channels, self.frames)
+        if host_out is None:
+            host_out = self.pinned((self.nstreams, self.channels, self.out_frames))
+        assert host_out.dtype == self.dtype and host_out.flags.c_contiguous
+        _check(self.L.pv_hostio_run(self.h, host_in.ctypes.data, host_out.ctypes.data), "pv_hostio_run")
+        return host_out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pv_hostio_destroy(self.h)
+            self.h = None
+        for p in getattr(self, "_pinned", []):
+            self.L.pv_host_free(p)
+        self._pinned = []
+
+    def __del__(self):
+        self.close()

@@ -200,6 +200,44 @@ def verify_outputs(torch, batch, d_in, out, dup_pairs, sample_streams, kw, flush
     return res
 
 
+def host_io_leg(torch, E, args, kw, flush, device_index, d_in, d_out_ref, steps=2):
+    """The same job with the staging included (never `value`): inputs and outputs in page-locked host memory, groups
+    of streams triple-buffered through the GPU (H2D / kernels / D2H overlapped), float32 and int16 on the wire."""
+    frames = args.seconds * 48000
+    res = {}
+    x_host = d_in.cpu().numpy()
+    for wire in ("f32", "i16"):
+        h = E.HostIO(args.streams, frames, channels=2, block=480, flush=flush, device=device_index,
+                     streams_per_group=args.host_io_group, wire=wire, **kw)
+        hin = h.pinned((args.streams, 2, frames))
+        if wire == "f32":
+            hin[...] = x_host
+        else:
+            hin[...] = np.round(x_host * 32768.0).astype(np.int16)  # the inputs sit on the int16 grid: exact
+        hout = h.pinned((args.streams, 2, h.out_frames))
+        h.run(hin, hout)  # warm-up
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            h.run(hin, hout)
+        dt = (time.perf_counter() - t0) / steps
+        ref = d_out_ref.cpu().numpy()
+        if wire == "f32":
+            same = bool(np.array_equal(hout.view(np.uint32), ref.view(np.uint32)))
+        else:
+            v = np.clip(ref * np.float32(32768.0), -32768.0, 32767.0)
+            same = bool(np.array_equal(hout, np.trunc(v).astype(np.int16)))
+        bytes_each_way = args.streams * 2 * frames * hin.itemsize
+        res[wire] = {"Msamples_s": round(args.streams * 2 * frames / dt / 1e6, 1),
+                     "x_realtime": round(args.streams * args.seconds / dt, 1), "ms_per_step": round(dt * 1e3, 2),
+                     "pcie_GBps_each_way": round(bytes_each_way / dt / 1e9, 2),
+                     "equals_device_resident_output": same}
+        h.close()
+    res["streams_per_group"] = args.host_io_group
+    res["note"] = ("host buffers page-locked; three groups in flight (copy-in / kernels / copy-out on three HIP "
+                   "streams); int16 converted on the device as the reference's WAV reader / writer do")
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +256,9 @@ def main():
     ap.add_argument("--groups", type=int, default=1,
                     help="split the streams into this many batches run concurrently on separate HIP streams")
     ap.add_argument("--sample-every", type=int, default=8, help="instrument every n-th chunk with HIP events")
+    ap.add_argument("--host-io", action="store_true",
+                    help="also measure the host-staged path (page-locked host in / out, H2D / kernels / D2H overlapped)")
+    ap.add_argument("--host-io-group", type=int, default=32, help="streams per staged group of the --host-io leg")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -315,6 +356,8 @@ def main():
                            "exact integer checksum of the whole batch equal after warm-up and after the timed steps")
 
     host_io = None
+    if args.host_io:
+        host_io = host_io_leg(torch, E, args, kw, cfg_flush, local_rank, d_in, out_all)
 
     if rank == 0:
         total_streams = args.streams * world

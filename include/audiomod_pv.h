@@ -159,6 +159,30 @@ int pv_batch_enable_timing(pv_batch *b, int on);
 int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launches[PV_NUM_KERNELS]);
 const char *pv_kernel_name(int k);
 
+/* ----------------------------------------------------------------------------------------------
+ * Host-staged many-stream job.  The reference's callers hold their audio in host memory (planar
+ * float buffers filled from 16-bit WAV data: main/main.cc:152-162,484-491; main/wavfile.cc:733-755,
+ * 1295-1306,1334-1342), so this is the batch engine with the staging included: `nstreams` streams in
+ * host memory, processed in groups of `streams_per_group` whose host-to-device copy, kernels and
+ * device-to-host copy overlap (three groups in flight on three HIP streams).  On the wire the
+ * samples are float32, or int16 exactly as the reference's WAV reader / writer convert them
+ * (in: int16 * 1/32768; out: saturate(x * 32768, -32768, 32767) truncated toward zero).
+ *   host_in  : [nstreams][channels][frames]      float32 or int16
+ *   host_out : [nstreams][channels][out_frames]  same type
+ * Both should be page-locked (pv_host_alloc) for the copies to run at PCIe rate and asynchronously.
+ * pv_hostio_run is synchronous: it returns when host_out is complete.
+ * -------------------------------------------------------------------------------------------- */
+#define PV_WIRE_F32 0
+#define PV_WIRE_I16 1
+typedef struct pv_hostio pv_hostio;
+int pv_hostio_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int32_t block, int32_t flush, int device,
+                     int32_t streams_per_group, int32_t wire, pv_hostio **out);
+void pv_hostio_destroy(pv_hostio *h);
+int64_t pv_hostio_out_frames(const pv_hostio *h);
+int pv_hostio_run(pv_hostio *h, const void *host_in, void *host_out);
+void *pv_host_alloc(size_t bytes); /* page-locked host memory (NULL on failure) */
+void pv_host_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -571,7 +571,7 @@ np.savez(sys.argv[1], *outs)
 """ % (ROOT,)
     with tempfile.TemporaryDirectory() as d:
         files = []
-        for tag, env in (("fused", {"AUDIOMOD_PV_FUSED": "1"}), ("tiles", {"AUDIOMOD_PV_FUSED": "0"})):
+        for tag, env in (("fused", {"AUDIOMOD_PV_FUSED": "2"}), ("tiles", {"AUDIOMOD_PV_FUSED": "0"})):
             f = os.path.join(d, tag + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,
                                env=dict(os.environ, **env), timeout=900)
