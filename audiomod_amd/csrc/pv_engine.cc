@@ -1092,6 +1092,25 @@ int pv_plan_simulate(const pv_config *cfg, const int32_t *n, int32_t ncalls, int
     return PV_OK;
 }
 
+int64_t pv_plan_table(const pv_config *cfg, int which, float *out, int64_t max) {
+    g_last_error.clear();
+    plan_reason_clear();
+    if (!cfg || max < 0 || (max > 0 && !out)) return -(int64_t)PV_ERR_INVALID_ARG;
+    Derived d;
+    const int st = derive(*cfg, d);
+    if (st != PV_OK) return -(int64_t)st;
+    if (which == PV_TABLE_CARRIER) {
+        CarrierGen gen((float)cfg->sample_rate, cfg->mode == PV_MODE_VOCODER_CHORD);
+        for (int64_t i = 0; i < max; ++i) out[i] = gen.next();
+        return max;
+    }
+    const std::vector<float> *t = which == PV_TABLE_WINDOW ? &d.window : which == PV_TABLE_SINC ? &d.sinc : nullptr;
+    if (!t) return -(int64_t)PV_ERR_INVALID_ARG;
+    const int64_t n = (int64_t)t->size() < max ? (int64_t)t->size() : max;
+    if (n > 0) memcpy(out, t->data(), (size_t)n * sizeof(float));
+    return (int64_t)t->size();
+}
+
 int pv_plan_whisper_phases(int64_t n, float *out) {
     if (n < 0 || (n > 0 && !out)) return PV_ERR_INVALID_ARG;
     WhisperRng rng;

@@ -94,88 +94,94 @@ static int make_fft(int nc, FftPlan &p) {
 // KAISER8 :233-240 with oversample 32 :262, compute_func :300-322, sinc :325-337,
 // update_filter :661-775)
 // ------------------------------------------------------------------------------------------
+// (the window table is data; it is what defines the filter)
 static const double kKaiser8[36] = {
     0.99635258, 1.00000000, 0.99635258, 0.98548012, 0.96759014, 0.94302200, 0.91223751, 0.87580811, 0.83439927,
     0.78875245, 0.73966538, 0.68797126, 0.63451750, 0.58014482, 0.52566725, 0.47185369, 0.41941150, 0.36897272,
     0.32108304, 0.27619388, 0.23465776, 0.19672670, 0.16255380, 0.13219758, 0.10562887, 0.08273982, 0.06335451,
     0.04724088, 0.03412321, 0.02369490, 0.01563093, 0.00959968, 0.00527363, 0.00233883, 0.00050000, 0.00000000};
 
-static double kaiser8_at(float x) {
-    float y = x * 32;
-    int ind = (int)std::floor(y);
-    float frac = (y - ind);
-    double c3 = -0.1666666667 * frac + 0.1666666667 * (frac * frac * frac);
-    double c2 = frac + 0.5 * (frac * frac) - 0.5 * (frac * frac * frac);
-    double c0 = -0.3333333333 * frac + 0.5 * (frac * frac) - 0.1666666667 * (frac * frac * frac);
-    double c1 = 1.f - c3 - c2 - c0;
-    return c0 * kKaiser8[ind] + c1 * kKaiser8[ind + 1] + c2 * kKaiser8[ind + 2] + c3 * kKaiser8[ind + 3];
+// Arithmetic contract (resample.c:300-322): the window value at u in [0, 1] is a 4-point cubic through the table
+// at spacing 1/32, with these weights -- float position and fraction, double weights, this operand order.
+static double kaiser8_window(float u) {
+    const float pos = u * 32;
+    const int cell = (int)std::floor(pos);
+    const float f = pos - cell;
+    const float f2 = f * f, f3 = f * f * f;
+    const double w_hi = -0.1666666667 * f + 0.1666666667 * f3;
+    const double w_mid = f + 0.5 * f2 - 0.5 * f3;
+    const double w_lo = -0.3333333333 * f + 0.5 * f2 - 0.1666666667 * f3;
+    const double w_rest = 1.f - w_hi - w_mid - w_lo;
+    const double *t = kKaiser8 + cell;
+    return w_lo * t[0] + w_rest * t[1] + w_mid * t[2] + w_hi * t[3];
 }
 
-static float sinc_tap(float cutoff, float x, int n) {
-    float xx = x * cutoff;
+// One tap of the windowed sinc (resample.c:325-337): x in input samples from the centre, taps = filter length.
+// Arithmetic contract: float product cutoff * x, double sine and quotient, window at float |2x / taps|.
+static float filter_tap(float cutoff, float x, int taps) {
     if (std::fabs(x) < 1e-6) return cutoff;
-    if (std::fabs(x) > .5 * n) return 0;
-    return (float)(cutoff * std::sin(M_PI * xx) / (M_PI * xx) * kaiser8_at((float)std::fabs(2. * x / n)));
+    if (std::fabs(x) > .5 * taps) return 0;
+    const float arg = x * cutoff;
+    return (float)(cutoff * std::sin(M_PI * arg) / (M_PI * arg) * kaiser8_window((float)std::fabs(2. * x / taps)));
 }
 
 static uint32_t gcd_u32(uint32_t a, uint32_t b) {
     while (b) {
-        uint32_t t = b;
-        b = a % b;
-        a = t;
+        const uint32_t r = a % b;
+        a = b;
+        b = r;
     }
     return a;
 }
 
-static void make_resampler(Derived &d) {
-    // RS_Speex::setratio (reference dsp/resampler.cc:740-770): ratio -> fraction over 272408136
-    const float ratio = (float)(1.0 / d.pitch_scale); // writeSlice passes 1.0 / m_pitchScale (phasevocoderprocess.cc:1174)
-    d.res_ratio = ratio;
-    const uint32_t big = 272408136U;
-    uint32_t denom = 1, num = 1;
-    if (ratio < 1.f) {
-        denom = big;
-        double dnum = double(big) * double(ratio);
-        num = (uint32_t)dnum;
-    } else if (ratio > 1.f) {
-        num = big;
-        double ddenom = double(big) / double(ratio);
-        denom = (uint32_t)ddenom;
+// The stream rate pair of the resampler that writeSlice feeds (phasevocoderprocess.cc:1174 passes 1 / pitchScale):
+// the ratio becomes a fraction over 272408136 with the other term truncated from a double product / quotient
+// (dsp/resampler.cc:746-757), handed over as (input rate, output rate) and reduced (resample.c:1136-1139).
+static void stream_rates(float out_per_in, uint32_t &num_rate, uint32_t &den_rate) {
+    const uint32_t unit = 272408136U;
+    num_rate = den_rate = 1;
+    if (out_per_in < 1.f) {
+        num_rate = unit;
+        den_rate = (uint32_t)(double(unit) * double(out_per_in));
+    } else if (out_per_in > 1.f) {
+        num_rate = (uint32_t)(double(unit) / double(out_per_in));
+        den_rate = unit;
     }
-    uint32_t num_rate = denom, den_rate = num; // speex_resampler_set_rate_frac(st, denom, num, ...)
-    uint32_t g = gcd_u32(num_rate, den_rate);
+    const uint32_t g = gcd_u32(num_rate, den_rate);
     num_rate /= g;
     den_rate /= g;
-    d.res_num = num_rate;
-    d.res_den = den_rate;
-    uint32_t oversample = 8, filt_len = 64;
-    float cutoff;
+}
+
+// Quality 4 of the Speex table: 64 taps, 8x oversampling, Kaiser-8 window, bandwidth 0.921 when down-sampling and
+// 0.940 when up-sampling (resample.c:290); down-sampling stretches the filter and narrows the cutoff by the rate
+// ratio and coarsens the oversampling for large ratios (:671-697).
+static void make_resampler(Derived &d) {
+    d.res_ratio = (float)(1.0 / d.pitch_scale);
+    stream_rates(d.res_ratio, d.res_num, d.res_den);
+    const uint32_t num_rate = d.res_num, den_rate = d.res_den;
+    uint32_t taps = 64, oversample = 8;
+    float cutoff = 0.940f;
     if (num_rate > den_rate) {
         cutoff = 0.921f * den_rate / num_rate;
-        filt_len = (uint32_t)std::ceil(filt_len * ((double)num_rate / (double)den_rate));
-        filt_len &= (~0x3u);
-        if (2 * den_rate < num_rate) oversample >>= 1;
-        if (4 * den_rate < num_rate) oversample >>= 1;
-        if (8 * den_rate < num_rate) oversample >>= 1;
-        if (16 * den_rate < num_rate) oversample >>= 1;
+        taps = (uint32_t)std::ceil(taps * ((double)num_rate / (double)den_rate)) & ~0x3u;
+        // (four independent 32-bit tests, as upstream: 16 * den_rate wraps for rates just below 272408136)
+        for (uint32_t fold : {2u, 4u, 8u, 16u})
+            if (fold * den_rate < num_rate) oversample >>= 1;
         if (oversample < 1) oversample = 1;
-    } else {
-        cutoff = 0.940f;
     }
-    d.filt_len = (int)filt_len;
+    d.filt_len = (int)taps;
     d.oversample = (int)oversample;
-    if (den_rate <= oversample) {
-        d.interp = false;
-        d.sinc.assign((size_t)filt_len * den_rate, 0.f);
-        for (uint32_t i = 0; i < den_rate; i++)
-            for (int j = 0; j < (int)filt_len; j++)
-                d.sinc[i * filt_len + j] =
-                    sinc_tap(cutoff, ((j - (int)filt_len / 2 + 1) - ((float)i) / den_rate), (int)filt_len);
+    d.interp = den_rate > oversample; // few distinct phases: one exact filter per phase instead of interpolation
+    const int half = (int)taps / 2;
+    if (!d.interp) {
+        d.sinc.assign((size_t)taps * den_rate, 0.f);
+        for (uint32_t phase = 0; phase < den_rate; ++phase)
+            for (int j = 0; j < (int)taps; ++j)
+                d.sinc[phase * taps + j] = filter_tap(cutoff, (j - half + 1) - ((float)phase) / den_rate, (int)taps);
     } else {
-        d.interp = true;
-        d.sinc.assign((size_t)filt_len * oversample + 8, 0.f);
-        for (int i = -4; i < (int)(oversample * filt_len + 4); i++)
-            d.sinc[i + 4] = sinc_tap(cutoff, (i / (float)oversample - filt_len / 2), (int)filt_len);
+        const int n = (int)(oversample * taps);
+        d.sinc.assign((size_t)n + 8, 0.f);
+        for (int i = -4; i < n + 4; ++i) d.sinc[(size_t)(i + 4)] = filter_tap(cutoff, i / (float)oversample - half, (int)taps);
     }
     d.int_adv = (int)(num_rate / den_rate);
     d.frac_adv = (int)(num_rate % den_rate);
@@ -226,24 +232,23 @@ int derive(const pv_config &cfg, Derived &d) {
     if (d.time_ratio <= 0.0) d.time_ratio = 1.0;
     const float hsr = d.time_ratio * d.pitch_scale;
     d.hs_ratio = hsr;
+    // Hops (calculateSizes, phasevocoderimpl.cc:196-226).  A caller-chosen input hop fixes the output hop; otherwise
+    // the window-to-hop ratio depends on which way the slices move: when they shrink (hsr < 1) the INPUT hop is
+    // window / 4.5 (pitch down) or window / 6 and the output hop follows; when they grow or stay, the OUTPUT hop is
+    // window / 8 (window / 4 at exactly 1) and the input hop follows.  Arithmetic contract: float quotients and
+    // products truncated through int.
     size_t inHop, outHop;
     if (cfg.hopsize > 0) {
         inHop = (size_t)cfg.hopsize;
         outHop = (size_t)int(std::floor(inHop * hsr));
+    } else if (hsr < 1) {
+        const float window_per_hop = d.pitch_scale < 1.0 ? 4.5f : 6.f;
+        inHop = (size_t)int(windowSize / window_per_hop);
+        outHop = (size_t)int(inHop * hsr);
     } else {
-        float wir = 4.5;
-        if (hsr < 1) {
-            if (hsr == 1.0) wir = 4;
-            else if (d.pitch_scale < 1.0) wir = 4.5;
-            else wir = 6;
-            inHop = (size_t)int(windowSize / wir);
-            outHop = (size_t)int(inHop * hsr);
-        } else {
-            if (hsr == 1.0) wir = 4;
-            else wir = 8;
-            outHop = (size_t)int(windowSize / wir);
-            inHop = (size_t)int(outHop / hsr);
-        }
+        const float window_per_hop = hsr == 1.0 ? 4.f : 8.f;
+        outHop = (size_t)int(windowSize / window_per_hop);
+        inHop = (size_t)int(outHop / hsr);
     }
     if (inHop < 1 || inHop > windowSize) return PV_ERR_INVALID_ARG;
     d.N = (int)windowSize;
@@ -305,25 +310,24 @@ int derive(const pv_config &cfg, Derived &d) {
 // ------------------------------------------------------------------------------------------
 // Planner
 // ------------------------------------------------------------------------------------------
-// calculateThisIncrement (phasevocoderprocess.cc:379-410) + calculateIncrements (:461-487)
+// The shift increment of the next slice (calculateThisIncrement, phasevocoderprocess.cc:379-410).  The ideal
+// output hop, hop * ratio, is rarely an integer; the increments are integers that follow it, a running "divergence"
+// keeps the accumulated difference and a recovery term pulls the next increment back by the divergence spread over
+// a tenth of a second's worth of slices.  Arithmetic contract: `ideal` is a float product; the recovery divides a
+// float by a double and is stored as float; lrint (half to even) of float expressions; clamp to [ideal/2, 2 ideal].
 int Planner::next_increment() {
-    const float ratio = d_.hs_ratio;
-    const size_t increment = (size_t)d_.hop;
-    const size_t samplerate = (size_t)d_.cfg.sample_rate;
-    recovery_ = divergence_ / ((samplerate / 10.0) / increment);
-    int incr = (int)std::lrint(increment * ratio - recovery_);
-    if (incr < std::lrint((increment * ratio) / 2)) {
-        incr = (int)std::lrint((increment * ratio) / 2);
-    } else if (incr > std::lrint(increment * ratio * 2)) {
-        incr = (int)std::lrint(increment * ratio * 2);
-    }
-    float divdiff = (increment * ratio) - incr;
-    float prev = divergence_;
-    divergence_ -= divdiff;
-    if ((prev < 0 && divergence_ > 0) || (prev > 0 && divergence_ < 0)) {
-        recovery_ = divergence_ / ((samplerate / 10.0) / increment);
-    }
-    return incr;
+    const float ideal = (size_t)d_.hop * d_.hs_ratio;
+    const double slices_per_tenth = ((size_t)d_.cfg.sample_rate / 10.0) / (size_t)d_.hop;
+    recovery_ = divergence_ / slices_per_tenth;
+    const long lowest = std::lrint(ideal / 2), highest = std::lrint(ideal * 2);
+    long step = std::lrint(ideal - recovery_);
+    if (step < lowest) step = lowest;
+    else if (step > highest) step = highest;
+    const float before = divergence_;
+    divergence_ -= ideal - (int)step;
+    const bool crossed_zero = (before < 0 && divergence_ > 0) || (before > 0 && divergence_ < 0);
+    if (crossed_zero) recovery_ = divergence_ / slices_per_tenth;
+    return (int)step;
 }
 
 static thread_local const char *g_plan_reason = "";
@@ -442,45 +446,40 @@ int plan_batch(const Derived &d, int64_t frames, int block, bool flush, BatchPla
     return PV_OK;
 }
 
+// Rosenberg glottal pulse (gen/rosenberg.cc:19-53): per period of round(sample_rate / f) samples an opening phase
+// of n1 = round(alpha * period) samples, 0.5 (1 - cos(pi n / n1)), a closing phase of n2 = round(beta * period)
+// samples, cos(pi (n - n1) / (2 n2)), then silence; the sample counter runs 0 .. period inclusive.  Arithmetic
+// contract: reciprocals stored as float (1 / n1 in float, 0.5 / n2 in double), cosf of a float argument formed in
+// double, the opening phase scaled in double.  (n1 = 0 at low sample rates makes the reference emit NaN: kept.)
 void CarrierGen::init(Voice &v, float sample_rate, float freq, float alpha, float beta) {
-    v.period = (int)std::round(1.f / freq * sample_rate);
     v.phase = 0;
+    v.period = (int)std::round(1.f / freq * sample_rate);
     v.n1 = (int)std::round(alpha * v.period);
-    v.inv_n1 = 1.f / static_cast<float>(v.n1);
     v.n2 = (int)std::round(beta * v.period);
+    v.inv_n1 = 1.f / static_cast<float>(v.n1);
     v.inv_2n2 = (float)(0.5 / static_cast<float>(v.n2));
 }
 
 float CarrierGen::step(Voice &v) {
-    float res = 0;
-    if (v.phase <= v.n1) {
-        res = (float)(0.5 * (1 - cosf((float)(M_PI * v.phase * v.inv_n1))));
-    } else if (v.phase - v.n1 <= v.n2) {
-        res = cosf((float)(M_PI * (v.phase - v.n1) * v.inv_2n2));
-    } else {
-        res = 0;
-    }
-    if (++v.phase > v.period) v.phase = 0;
-    return res;
+    const int n = v.phase;
+    v.phase = n + 1 > v.period ? 0 : n + 1;
+    if (n <= v.n1) return (float)(0.5 * (1 - cosf((float)(M_PI * n * v.inv_n1))));
+    if (n - v.n1 <= v.n2) return cosf((float)(M_PI * (n - v.n1) * v.inv_2n2));
+    return 0;
 }
 
-CarrierGen::CarrierGen(float sample_rate, bool chord) {
-    const float alpha = 0.01f, beta = 0.06f;
-    if (chord) {
-        const float f[3] = {440, 523.251f, 659.255f};
-        nv_ = 3;
-        for (int i = 0; i < 3; ++i) init(v_[i], sample_rate, f[i], alpha, beta);
-    } else {
-        nv_ = 1;
-        init(v_[0], sample_rate, 440, alpha, beta);
-    }
+// one voice at 440 Hz, or the A-minor triad 440 / 523.251 / 659.255 Hz averaged (rosenbergchord.cc:19-43); both
+// scaled by 0.3 in double (phasevocoderprocess.cc:96-107)
+CarrierGen::CarrierGen(float sample_rate, bool chord) : nv_(chord ? 3 : 1) {
+    static const float kTriad[3] = {440, 523.251f, 659.255f};
+    for (int i = 0; i < nv_; ++i) init(v_[i], sample_rate, kTriad[i], 0.01f, 0.06f);
 }
 
 float CarrierGen::next() {
     if (nv_ == 1) return (float)(step(v_[0]) * 0.3);
-    float res = 0;
-    for (int i = 0; i < 3; ++i) res += step(v_[i]) / 3;
-    return (float)(res * 0.3);
+    float mix = 0;
+    for (int i = 0; i < nv_; ++i) mix += step(v_[i]) / 3;
+    return (float)(mix * 0.3);
 }
 
 // glibc rand(): TYPE_3 additive feedback generator x[i] = x[i-3] + x[i-31] (mod 2^32), output x >> 1, state

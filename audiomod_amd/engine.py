@@ -78,6 +78,8 @@ def lib():
     L.pv_plan_simulate.argtypes = [C.POINTER(Config), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int64, C.POINTER(C.c_int64), C.POINTER(Info)]
     L.pv_plan_whisper_phases.argtypes = [C.c_int64, C.c_void_p]
+    L.pv_plan_table.argtypes = [C.POINTER(Config), C.c_int, C.c_void_p, C.c_int64]
+    L.pv_plan_table.restype = C.c_int64
     L.pv_create.argtypes = [C.POINTER(Config), C.c_int, C.POINTER(C.c_void_p)]
     L.pv_destroy.argtypes = [C.c_void_p]
     L.pv_feed.argtypes = [C.c_void_p, fpp, C.c_int32]
@@ -141,6 +143,16 @@ def plan_simulate(calls, max_slices=1 << 22, **kw):
     _check(st, "pv_plan_simulate")
     k = min(ns.value, max_slices)
     return avail, shift[:k], phase[:k], info.as_dict()
+
+
+def plan_table(which, max_len=1 << 20, **kw):
+    """The planner's window (0), Speex filter table (1) or vocoder carrier (2: first max_len samples); host only."""
+    cfg = make_config(**kw)
+    out = np.zeros(max_len, np.float32)
+    n = lib().pv_plan_table(C.byref(cfg), which, out.ctypes.data, max_len)
+    if n < 0:
+        _check(int(-n), "pv_plan_table")
+    return out[:min(n, max_len)].copy()
 
 
 def whisper_phases(n):

@@ -95,6 +95,15 @@ int pv_plan_simulate(const pv_config *cfg, const int32_t *n, int32_t ncalls, int
 /* The first n phases WHISPER mode assigns in a fresh reference process (glibc rand() from its default seed;
  * reference phasevocoderprocess.cc:814-822), in draw order: slice-major, channel, bin 0..N/2. */
 int pv_plan_whisper_phases(int64_t n, float *out);
+/* The data-independent float tables the planner derives for a configuration, for tests and inspection (no GPU
+ * needed): PV_TABLE_WINDOW = the Hann window (windowfunc.h:159-169); PV_TABLE_SINC = the Speex Q4 filter table
+ * (resample.c:661-775; empty when the configuration does not resample); PV_TABLE_CARRIER = the first `max` samples of
+ * the vocoder carrier (gen/rosenberg.cc, rosenbergchord.cc).  Writes min(len, max) floats, returns the table's
+ * length (PV_TABLE_CARRIER: max), or a negative pv_status. */
+#define PV_TABLE_WINDOW 0
+#define PV_TABLE_SINC 1
+#define PV_TABLE_CARRIER 2
+int64_t pv_plan_table(const pv_config *cfg, int which, float *out, int64_t max);
 
 /* ----------------------------------------------------------------------------------------------
  * Streaming engine: ONE stream of cfg->channels planar channels, host buffers in and out.

@@ -175,3 +175,34 @@ def test_fails_loudly_without_gpu():
         E.PhaseVocoder(48000, 2, 1.0, 4.0)
     with pytest.raises(E.PvError, match="no gfx950"):
         E.Batch(2, 48000, semitones=4.0)
+
+
+@pytest.mark.parametrize("st", [0.1, 0.37, 1.0, 4.0, 7.0, -0.2, -7.0, 12.0, -12.0, 15.9, -15.9])
+def test_planner_filter_table_is_the_oracles(st):
+    """The Speex Q4 rate pair, filter geometry and every coefficient of the table the planner derives (pv_plan.cc
+    make_resampler; uploaded for the resampling kernels) against the oracle's, which is pinned on the compiled
+    reference (resample.c:661-775): bit for bit."""
+    import ctypes as C
+    info = E.plan_simulate([480], channels=1, semitones=st)[3]
+    tab = E.plan_table(1, channels=1, semitones=st)
+    L = O.lib()
+    r = L.pvo_res_create()
+    x, buf = np.zeros(256, np.float32), np.zeros(4096, np.float32)
+    L.pvo_res_process(r, x.ctypes.data, 256, C.c_float(1.0 / info["pitch_scale"]), buf.ctypes.data)
+    n = L.pvo_res_table(r, None, 0)
+    want = np.zeros(n, np.float32)
+    L.pvo_res_table(r, want.ctypes.data, n)
+    num, den, fl, ov, it = C.c_uint(), C.c_uint(), C.c_int(), C.c_int(), C.c_int()
+    L.pvo_res_info(r, C.byref(num), C.byref(den), C.byref(fl), C.byref(ov), C.byref(it))
+    L.pvo_res_destroy(r)
+    assert (info["res_num"], info["res_den"], info["res_filt_len"], info["res_oversample"], info["res_interp"]) == \
+        (num.value, den.value, fl.value, ov.value, it.value)
+    assert tab.shape == want.shape and np.array_equal(tab.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("N", [256, 2048, 4096, 8192])
+def test_planner_window_is_the_oracles(N):
+    win = E.plan_table(0, channels=1, fftsize=N)
+    want, area = np.zeros(N, np.float32), np.zeros(1, np.float32)
+    O.lib().pvo_hann(N, want.ctypes.data, area.ctypes.data)
+    assert np.array_equal(win.view(np.uint32), want.view(np.uint32))
