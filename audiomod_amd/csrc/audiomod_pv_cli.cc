@@ -40,17 +40,27 @@ struct WavIn {
             fclose(f);
             throw std::runtime_error("not a RIFF/WAVE file");
         }
+        // chunk lengths come from the file: never allocate or skip by more than the file still holds
+        long file_size = 0;
+        if (fseek(f, 0, SEEK_END) == 0) file_size = ftell(f);
+        fseek(f, 12, SEEK_SET);
         bool have_fmt = false, have_data = false;
+        int block_align = 0;
         while (!have_data) {
             unsigned char ch[8];
             if (fread(ch, 1, 8, f) != 8) break;
             const uint32_t len = ch[4] | (ch[5] << 8) | (ch[6] << 16) | ((uint32_t)ch[7] << 24);
+            const long here = ftell(f);
+            const long remaining = here >= 0 && file_size > here ? file_size - here : 0;
             if (!memcmp(ch, "fmt ", 4)) {
+                if (len < 16 || len > 4096 || (long)len > remaining) break; // a format chunk is 16-40 bytes
                 std::vector<unsigned char> b(len);
-                if (fread(b.data(), 1, len, f) != len || len < 16) break;
+                if (fread(b.data(), 1, len, f) != len) break;
+                if (len & 1) fseek(f, 1, SEEK_CUR); // chunks are word aligned: skip the pad byte
                 const int fmt = b[0] | (b[1] << 8);
                 channels = b[2] | (b[3] << 8);
                 rate = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+                block_align = b[12] | (b[13] << 8);
                 bits = b[14] | (b[15] << 8);
                 if (fmt != 1) {
                     fclose(f);
@@ -58,17 +68,20 @@ struct WavIn {
                 }
                 have_fmt = true;
             } else if (!memcmp(ch, "data", 4)) {
-                data.resize(len);
-                const size_t got = fread(data.data(), 1, len, f);
+                const size_t want = (long)len > remaining ? (size_t)remaining : (size_t)len; // a truncated file: what is there
+                data.resize(want);
+                const size_t got = want ? fread(data.data(), 1, want, f) : 0;
                 data.resize(got);
                 have_data = true;
             } else {
-                fseek(f, (long)len + (len & 1), SEEK_CUR);
+                const long skip = (long)len + (len & 1);
+                if (skip > remaining || fseek(f, skip, SEEK_CUR) != 0) break;
             }
         }
         fclose(f);
-        if (!have_fmt || !have_data || channels < 1 || (bits != 8 && bits != 16 && bits != 24 && bits != 32))
-            throw std::runtime_error("unsupported or truncated WAV file");
+        if (!have_fmt || !have_data || channels < 1 || (bits != 8 && bits != 16 && bits != 24 && bits != 32) ||
+            block_align != channels * bits / 8)
+            throw std::runtime_error("unsupported, inconsistent or truncated WAV file");
         frames = (long)(data.size() / (size_t)(channels * bits / 8));
     }
 

@@ -298,6 +298,10 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     S = nstreams;
     C = cfg.channels;
     rows = S * C;
+    if (rows > 65535) { // several kernels put the rows on grid.y
+        g_last_error = "more than 65535 rows (streams x channels) in one batch: split it";
+        return PV_ERR_UNSUPPORTED;
+    }
     HP = d.hs + 8; // row pitch of the mag / phase planes (16-byte aligned rows)
     pkmax = d.hs / 3 + 2;
     PKP = (pkmax + 7) & ~7;

@@ -482,12 +482,17 @@ template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyz
     analyze_wave_role<NC>(a, row, tl, lds);
 }
 
-// kernels may need more than the default 64 KiB of dynamic LDS at the largest FFT sizes
-template <typename K> static void allow_big_lds(K kernel, bool &done) {
-    if (done) return;
+// Kernels may need more than the default 64 KiB of dynamic LDS.  hipFuncSetAttribute applies to the device that is
+// current at the call, so the "done" mark is kept per kernel AND device (a bit per device index; atomics because two
+// host threads may launch for the first time together -- setting the attribute twice is harmless).
+template <typename K> static void allow_big_lds_dev(K kernel, unsigned long long &done_mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(&done_mask, __ATOMIC_ACQUIRE) & bit) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024 - 512);
-    done = true;
+    __atomic_fetch_or(&done_mask, bit, __ATOMIC_RELEASE);
 }
 
 void launch_analyze(const AnalyzeArgs &a, hipStream_t st) {
@@ -500,8 +505,8 @@ void launch_analyze(const AnalyzeArgs &a, hipStream_t st) {
         } else {
             constexpr int WPB = 1;
             const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
-            static bool big = false;
-            allow_big_lds(pv_analyze_wave_kernel<2048, WPB>, big);
+            static unsigned long long big = 0;
+            allow_big_lds_dev(pv_analyze_wave_kernel<2048, WPB>, big);
             hipLaunchKernelGGL((pv_analyze_wave_kernel<2048, WPB>), dim3(grid), dim3(64 * WPB),
                                WPB * WF<2048>::LDS_CF * sizeof(cf), st, a);
         }
@@ -862,8 +867,8 @@ size_t seq_lds_bytes(const SeqArgs &a) { return sizeof(float) * ((size_t)2 * a.P
 void launch_seq(const SeqArgs &a, hipStream_t st) {
     const int nt = seq_threads(a.PKP);
     const size_t lds = seq_lds_bytes(a);
-    static bool big = false;
-    allow_big_lds(pv_seq_kernel, big);
+    static unsigned long long big = 0;
+    allow_big_lds_dev(pv_seq_kernel, big);
     hipLaunchKernelGGL(pv_seq_kernel, dim3(a.rows), dim3(nt), lds, st, a);
 }
 
@@ -1461,8 +1466,8 @@ void launch_synth(const SynthArgs &a, hipStream_t st) {
                 else hipLaunchKernelGGL((pv_synth_wave_kernel<1024, WPB, 2>), dim3(grid), dim3(64 * WPB), lds, st, a);
                 return;
             }
-            static bool big1 = false;
-            allow_big_lds(pv_synth_wave_kernel<1024, WPB>, big1);
+            static unsigned long long big1 = 0;
+            allow_big_lds_dev(pv_synth_wave_kernel<1024, WPB>, big1);
             hipLaunchKernelGGL((pv_synth_wave_kernel<1024, WPB>), dim3(grid), dim3(64 * WPB),
                                WPB * WF<1024>::LDS_CF * sizeof(cf), st, a);
         } else {
@@ -1477,8 +1482,8 @@ void launch_synth(const SynthArgs &a, hipStream_t st) {
                 else hipLaunchKernelGGL((pv_synth_wave_kernel<2048, WPB, 2>), dim3(grid), dim3(64 * WPB), lds, st, a);
                 return;
             }
-            static bool big2 = false;
-            allow_big_lds(pv_synth_wave_kernel<2048, WPB>, big2);
+            static unsigned long long big2 = 0;
+            allow_big_lds_dev(pv_synth_wave_kernel<2048, WPB>, big2);
             hipLaunchKernelGGL((pv_synth_wave_kernel<2048, WPB>), dim3(grid), dim3(64 * WPB),
                                WPB * WF<2048>::LDS_CF * sizeof(cf), st, a);
         }
@@ -1487,8 +1492,8 @@ void launch_synth(const SynthArgs &a, hipStream_t st) {
     const int grid = 8 * ((a.rows + 7) / 8) * a.Tn;
     const size_t lds = (size_t)(2 * a.tb.nc + 1) * sizeof(float2) + sizeof(float) * (a.tb.hs + 4 + a.PKP) +
                        sizeof(uint16_t) * a.PKP;
-    static bool big = false;
-    allow_big_lds(pv_synth_kernel, big);
+    static unsigned long long big = 0;
+    allow_big_lds_dev(pv_synth_kernel, big);
     hipLaunchKernelGGL(pv_synth_kernel, dim3(grid), dim3(kFftThreads), lds, st, a);
 }
 
@@ -1906,15 +1911,15 @@ size_t ola_lds_bytes(const OlaArgs &a, int rows_per_group) {
 void launch_ola(const OlaArgs &a, hipStream_t st) {
     const size_t lds = ola_lds_bytes(a, kOlaRows);
     const dim3 grid(a.ntiles, (a.rows + kOlaRows - 1) / kOlaRows);
-    static bool big0 = false, big1 = false, big2 = false;
+    static unsigned long long big0 = 0, big1 = 0, big2 = 0;
     if (!a.resample) {
-        allow_big_lds(pv_ola_kernel<0>, big0);
+        allow_big_lds_dev(pv_ola_kernel<0>, big0);
         hipLaunchKernelGGL(pv_ola_kernel<0>, grid, dim3(kTileOut), lds, st, a);
     } else if (!a.interp) {
-        allow_big_lds(pv_ola_kernel<1>, big1);
+        allow_big_lds_dev(pv_ola_kernel<1>, big1);
         hipLaunchKernelGGL(pv_ola_kernel<1>, grid, dim3(kTileOut), lds, st, a);
     } else {
-        allow_big_lds(pv_ola_kernel<2>, big2);
+        allow_big_lds_dev(pv_ola_kernel<2>, big2);
         hipLaunchKernelGGL(pv_ola_kernel<2>, grid, dim3(kTileOut), lds, st, a);
     }
 }
@@ -2293,17 +2298,6 @@ size_t chain_lds_bytes(const ChainArgs &a, int nc_wave) {
     return (size_t)a.waves * per_wave + chain_shared_bytes(a);
 }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel AND device
-template <typename K> static void allow_big_lds_dev(K kernel, unsigned long long &done_mask) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (__atomic_load_n(&done_mask, __ATOMIC_ACQUIRE) & bit) return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024 - 512);
-    __atomic_fetch_or(&done_mask, bit, __ATOMIC_RELEASE);
-}
-
 template <int NC, int kPlainCore> static void launch_synth_chain_res(const SynthArgs &s, const ChainArgs &c, hipStream_t st) {
     const size_t lds = chain_lds_bytes(c, NC);
     const dim3 grid(c.rows), block(64 * c.waves);
@@ -2526,12 +2520,12 @@ bool stream_kernel_supported(const StreamArgs &s) {
 void launch_stream(const StreamArgs &s, hipStream_t st) {
     const size_t lds = stream_lds_bytes(s);
     if (s.aa.tb.nc == 1024) {
-        static bool big1 = false;
-        allow_big_lds(pv_stream_kernel<1024>, big1);
+        static unsigned long long big1 = 0;
+        allow_big_lds_dev(pv_stream_kernel<1024>, big1);
         hipLaunchKernelGGL((pv_stream_kernel<1024>), dim3(1), dim3(kStreamThreads), lds, st, s);
     } else {
-        static bool big2 = false;
-        allow_big_lds(pv_stream_kernel<2048>, big2);
+        static unsigned long long big2 = 0;
+        allow_big_lds_dev(pv_stream_kernel<2048>, big2);
         hipLaunchKernelGGL((pv_stream_kernel<2048>), dim3(1), dim3(kStreamThreads), lds, st, s);
     }
 }

@@ -48,3 +48,34 @@ def test_cli_rejects_other_effects(tmp_path):
     open(fin, "wb").write(z["in_wav"].tobytes())
     r = subprocess.run([CLI, "reverb", fin, str(tmp_path / "o.wav")], capture_output=True, text=True)
     assert r.returncode != 0 and "not supported" in r.stderr
+
+
+def _wav(fmt_len=16, data_len=None, pad_fmt=False, block_align=None, claim_data=None, samples=b"\x00\x00" * 2000):
+    import struct
+    ch, rate, bits = 2, 48000, 16
+    ba = block_align if block_align is not None else ch * bits // 8
+    fmt = struct.pack("<HHIIHH", 1, ch, rate, rate * ba, ba, bits) + b"\x00" * (fmt_len - 16)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", fmt_len) + fmt + (b"\x00" if pad_fmt else b"")
+    body += b"data" + struct.pack("<I", claim_data if claim_data is not None else len(samples)) + samples
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+@pytest.mark.parametrize("name,blob,ok", [
+    ("odd fmt chunk with its pad byte", _wav(fmt_len=17, pad_fmt=True), True),
+    ("data length claims 4 GB", _wav(claim_data=0xFFFFFFF0), True),  # reads what the file holds
+    ("block align contradicts channels * bits", _wav(block_align=3), False),
+    ("fmt chunk claims 1 GB", _wav()[:16] + (1 << 30).to_bytes(4, "little") + _wav()[20:], False),
+])
+def test_cli_wav_reader_does_not_trust_chunk_lengths(name, blob, ok, tmp_path):
+    """Header fields come from the file: no allocation or seek beyond what the file holds, the pad byte after an
+    odd-length chunk is skipped, block-align must agree with channels * bits / 8.  (Runs the CLI up to the point
+    where it needs the GPU; without one a well-formed file fails with the no-device message, never with a crash.)"""
+    fin = tmp_path / "in.wav"
+    fin.write_bytes(blob)
+    r = subprocess.run([CLI, "normal_pitchshift", str(fin), str(tmp_path / "o.wav"), "4", "1", "2048"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode in (0, 1), (name, r.returncode, r.stderr[-300:])  # an error exit, not a signal
+    if not ok:
+        assert r.returncode != 0 and "WAV" in r.stderr, (name, r.stderr[-300:])
+    else:
+        assert "WAV file" not in r.stderr, (name, r.stderr[-300:])
