@@ -751,6 +751,13 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         qa.st_kind = st_kind.p;
         qa.st_rot = st_rot.p;
         qa.st_po = st_po.p;
+        {
+            static const int prio = [] {
+                const char *e = getenv("AUDIOMOD_PV_SEQ_PRIO");
+                return e ? atoi(e) : -1;
+            }();
+            qa.high_prio = prio >= 0 ? prio : 1; // (measured without: no difference, 56.6 vs 56.4 ms per step)
+        }
         if (single_launch) fused.qa = qa;
         else side_stream(PV_K_SEQ, [&](hipStream_t s) { launch_seq(qa, s); });
     } else if (cm == 0) {

@@ -78,6 +78,7 @@ struct MatchArgs {
 
 struct SeqArgs {
     int N, hs, HP, PKP, C, hop, TR, rows, Tn, s0;
+    int high_prio; // s_setprio(3): win every issue arbitration (when the chain's result is what everybody waits for)
     double two_pi_hop;
     int64_t t0;
     const int32_t *phase_inc;

@@ -852,7 +852,7 @@ __global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // the chain is pure latency and may share the GPU with the overlap-add tiles of the previous chunk (second
     // HIP stream): let its few waves win every issue arbitration
-    __builtin_amdgcn_s_setprio(3);
+    if (a.high_prio) __builtin_amdgcn_s_setprio(3);
     seq_role(a, blockIdx.x, smem_raw);
 }
 

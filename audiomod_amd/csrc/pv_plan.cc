@@ -393,6 +393,14 @@ int Planner::try_slice(std::vector<SliceRec> &out) {
         Kn = Pn;
     }
     r.cnt = (int32_t)(Kn - K_);
+    if (r.cnt > d_.outbuf_cap - out_fill_) {
+        // The guard above admits a slice by an estimate (CONSTANT mode: one input hop) that an up-sampling resampler
+        // exceeds: the reference's ring then takes only part of the slice's output and loses the rest
+        // (circularqueue.h:337-341).  A stream with samples missing mid-slice is not worth reproducing: refused.
+        g_plan_reason = "the reference's output ring would truncate a slice's output here (CONSTANT mode through an "
+                        "up-sampling resampler with more output pending than the ring holds): retrieve between calls";
+        return PV_ERR_OUTPUT_OVERRUN;
+    }
     out_fill_ += r.cnt;
     P_ = Pn;
     K_ = Kn;
