@@ -341,6 +341,13 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
             three_stage = pipelined_planes && d.resample && !(e3 && atoi(e3) == 0);
         }
         int wmax = d.fft.nc == 2048 ? 8 : ((pipelined_planes && !three_stage) ? 12 : 16);
+        {
+            // the all-modes synthesis variant is compiled for twelve waves (pv_kernels.hip pv_synth_chain_kernel)
+            const char *g = getenv("AUDIOMOD_PV_SYNTH_GENERIC"); // (tests: every mode through the all-modes variant)
+            const bool plain = !d.do_freq_comp && !d.vocoder && !d.robotic && !d.constant && !d.whisper &&
+                               !(g && atoi(g) != 0);
+            if (!plain && wmax > 12) wmax = 12;
+        }
         if (const char *e = getenv("AUDIOMOD_PV_CHAIN_WAVES")) { // tuning knob: upper bound of waves per workgroup
             const int v = atoi(e);
             if (v >= 1 && v < wmax) wmax = v;

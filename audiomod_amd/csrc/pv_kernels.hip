@@ -2208,8 +2208,11 @@ __device__ __forceinline__ void chain_slice_tail(const ChainArgs &c_in, const Ch
     }
 }
 
+// (the all-modes variant -- frequency compression, vocoder, ... -- needs ~150 VGPRs where the plain ones fit 128:
+// compiled for twelve waves per workgroup, three per SIMD, instead of spilling)
 template <int NC, int kPlainCore, int kRes>
-__global__ __launch_bounds__(NC == 1024 ? 1024 : 512) void pv_synth_chain_kernel(const SynthArgs s, const ChainArgs c) {
+__global__ __launch_bounds__(NC == 1024 ? (kPlainCore < 0 ? 768 : 1024) : 512) void pv_synth_chain_kernel(
+    const SynthArgs s, const ChainArgs c) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using W = WF<NC>;
     constexpr int N = 2 * NC, hs = NC, NQ = N / 4, NP = NQ / 64;
