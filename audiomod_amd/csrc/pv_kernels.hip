@@ -1081,6 +1081,10 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
         a.do_freq_comp = 0, a.voc_band_len = -1, a.robotic = 0, a.passthru = 0, a.whisper = nullptr;
         a.coremode = kPlainCore;
     }
+    // kPlainCore == 3: the formant / gender modes in the phase-locked core mode (frequency compression on, every
+    // other switch off), for the fused kernel: with twelve waves per workgroup it has the registers (round 1's fold
+    // spilled at 128)
+    if (kPlainCore == 3) a.do_freq_comp = 1, a.coremode = 1;
     using W = WF<NC>;
     constexpr int N = 2 * NC, hs = NC, R = W::R;
     // (a caller that loops over slices passes a lane id that is opaque per iteration, so that the lane-dependent
@@ -2211,7 +2215,7 @@ __device__ __forceinline__ void chain_slice_tail(const ChainArgs &c_in, const Ch
 // (the all-modes variant -- frequency compression, vocoder, ... -- needs ~150 VGPRs where the plain ones fit 128:
 // compiled for twelve waves per workgroup, three per SIMD, instead of spilling)
 template <int NC, int kPlainCore, int kRes>
-__global__ __launch_bounds__(NC == 1024 ? (kPlainCore < 0 ? 768 : 1024) : 512) void pv_synth_chain_kernel(
+__global__ __launch_bounds__(NC == 1024 ? ((kPlainCore < 0 || kPlainCore == 3) ? 768 : 1024) : 512) void pv_synth_chain_kernel(
     const SynthArgs s, const ChainArgs c) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using W = WF<NC>;
@@ -2317,8 +2321,11 @@ template <int NC, int kPlainCore> static void launch_synth_chain_res(const Synth
 void launch_synth_chain(const SynthArgs &s, const ChainArgs &c, hipStream_t st) {
     const bool plain = !s.do_freq_comp && s.voc_band_len < 0 && !s.robotic && !s.passthru && !s.whisper &&
                        !synth_generic_only() && s.coremode >= 0 && s.coremode <= 2;
+    const bool fc_locked = s.do_freq_comp && s.voc_band_len < 0 && !s.robotic && !s.passthru && !s.whisper &&
+                           !synth_generic_only() && s.coremode == 1;
     if (s.tb.nc == 1024) {
-        if (plain && s.coremode == 1) launch_synth_chain_res<1024, 1>(s, c, st);
+        if (fc_locked) launch_synth_chain_res<1024, 3>(s, c, st);
+        else if (plain && s.coremode == 1) launch_synth_chain_res<1024, 1>(s, c, st);
         else if (plain && s.coremode == 0) launch_synth_chain_res<1024, 0>(s, c, st);
         else if (plain) launch_synth_chain_res<1024, 2>(s, c, st);
         else launch_synth_chain_res<1024, -1>(s, c, st);
