@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "audiomod_pv.h"
+#include "pv_atan2f.h"
 
 namespace {
 
@@ -32,6 +33,13 @@ __global__ void pv_f32_to_i16(const float *__restrict__ in, int16_t *__restrict_
     out[i] = (int16_t)(int)v;
 }
 
+// the analysis kernels' atan2f (pv_atan2f.h, device build: short division) on arrays, for pv_debug_atan2f
+__global__ void pv_atan2f_probe(const float *__restrict__ y, const float *__restrict__ x, float *__restrict__ out,
+                                int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pv_atan2f_fd_finite(y[i], x[i]);
+}
+
 constexpr int kSlots = 3; // groups in flight
 
 } // namespace
@@ -48,6 +56,22 @@ struct pv_hostio {
 };
 
 extern "C" {
+
+int pv_debug_atan2f(const float *y, const float *x, float *out, int64_t n, int device) {
+    if (n < 0 || (n > 0 && (!y || !x || !out))) return PV_ERR_INVALID_ARG;
+    if (n == 0) return PV_OK;
+    float *d = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&d, (size_t)n * 3 * sizeof(float)) != hipSuccess)
+        return PV_ERR_HIP;
+    bool ok = hipMemcpy(d, y, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + n, x, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(pv_atan2f_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d, d + n, d + 2 * n, n);
+        ok = hipMemcpy(out, d + 2 * n, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d);
+    return ok ? PV_OK : PV_ERR_HIP;
+}
 
 void *pv_host_alloc(size_t bytes) {
     void *p = nullptr;

@@ -181,6 +181,10 @@ const char *pv_kernel_name(int k);
  * Both should be page-locked (pv_host_alloc) for the copies to run at PCIe rate and asynchronously.
  * pv_hostio_run is synchronous: it returns when host_out is complete.
  * -------------------------------------------------------------------------------------------- */
+/* Diagnostics: the analysis kernels' atan2f (libm's algorithm restated, audiomod_amd/csrc/pv_atan2f.h, device build)
+ * evaluated on host arrays of FINITE values -- tests compare it with the C library's atan2f bit for bit. */
+int pv_debug_atan2f(const float *y, const float *x, float *out, int64_t n, int device);
+
 #define PV_WIRE_F32 0
 #define PV_WIRE_I16 1
 typedef struct pv_hostio pv_hostio;

@@ -1288,3 +1288,9 @@ long pvo_get_increments(const pvo *h, int *shift, int *phase, long max) {
     if (phase) memcpy(phase, h->rec_phase, sizeof(int) * n);
     return h->nrec;
 }
+
+/* libm's atan2f over arrays (the analysis phases of the reference come from it, FFT.cc:2623-2630): what the
+ * device's restatement is compared with on the GPU box */
+void pvo_atan2f_array(const float *y, const float *x, float *out, long n) {
+    for (long i = 0; i < n; ++i) out[i] = atan2f(y[i], x[i]);
+}

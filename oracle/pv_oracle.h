@@ -83,4 +83,6 @@ int pvo_res_table(const pvo_resampler *r, float *dst, int max);
 #ifdef __cplusplus
 }
 #endif
+void pvo_atan2f_array(const float *y, const float *x, float *out, long n);
+
 #endif

@@ -660,3 +660,39 @@ print("transactional ok")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
                        env=dict(os.environ, AUDIOMOD_PV_FUSED="0"), timeout=600)
     assert r.returncode == 0 and "transactional ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_device_atan2f_is_libms_bit_for_bit():
+    """The analysis kernels' atan2f as the DEVICE computes it (its own short division, pv_atan2f.h) against the C
+    library's on the box: spectrum-like magnitudes, random finite bit patterns, every reduction threshold, zeros and
+    signed zeros.  (The host build of the same header is swept in tests/test_native_host.py.)"""
+    import ctypes as C
+    rng = np.random.default_rng(2024)
+    n = 6_000_000
+    parts_y, parts_x = [], []
+    e = rng.uniform(-8, 3, (2, n)).astype(np.float32)
+    sg = rng.choice(np.array([-1.0, 1.0], np.float32), (2, n))
+    parts_y.append((10.0 ** e[0]).astype(np.float32) * sg[0])
+    parts_x.append((10.0 ** e[1]).astype(np.float32) * sg[1])
+    bits = rng.integers(0, 2 ** 32, (2, n), dtype=np.uint64).astype(np.uint32)
+    fy, fx = bits[0].view(np.float32), bits[1].view(np.float32)
+    fin = np.isfinite(fy) & np.isfinite(fx)
+    parts_y.append(fy[fin])
+    parts_x.append(fx[fin])
+    for t in (0.4375, 0.6875, 1.1875, 2.4375, 1.0, 3.7e-9, 3.3554432e7):
+        r = (np.float32(t).view(np.uint32) + np.arange(-20000, 20001, dtype=np.int64)).astype(np.uint32).view(np.float32)
+        for xv in (1.0, 0.37, 123.456, -0.37, -5e-3):
+            parts_y += [r * np.float32(xv), -r * np.float32(xv)]
+            parts_x += [np.full_like(r, xv), np.full_like(r, xv)]
+    z = np.array([0.0, -0.0, 1.0, -1.0, 1e-45, -1e-45, 3.4e38, -3.4e38, 1e-30, 1e30], np.float32)
+    parts_y.append(np.repeat(z, len(z)))
+    parts_x.append(np.tile(z, len(z)))
+    y = np.ascontiguousarray(np.concatenate(parts_y), np.float32)
+    x = np.ascontiguousarray(np.concatenate(parts_x), np.float32)
+    got, want = np.zeros_like(y), np.zeros_like(y)
+    E._check(E.lib().pv_debug_atan2f(y.ctypes.data, x.ctypes.data, got.ctypes.data, len(y), 0), "pv_debug_atan2f")
+    L = O.lib()
+    L.pvo_atan2f_array.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+    L.pvo_atan2f_array(y.ctypes.data, x.ctypes.data, want.ctypes.data, len(y))
+    bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+    assert bad.size == 0, (bad.size, y[bad[:5]], x[bad[:5]], got[bad[:5]], want[bad[:5]])
