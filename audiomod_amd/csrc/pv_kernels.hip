@@ -474,6 +474,8 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
     for (int i = lane; 2 * i < running; i += 64) pk32[i] = slist32[i];
 }
 
+// (the 4096-point variant needs 232 VGPRs, two waves per SIMD; forced to three -- 168 registers, 88 spilled -- it is
+// slower: 1.05 vs 0.91 ms per 64 K slices)
 template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyze_wave_kernel(const AnalyzeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cf *lds = reinterpret_cast<cf *>(smem_raw) + (threadIdx.x >> 6) * WF<NC>::LDS_CF;
