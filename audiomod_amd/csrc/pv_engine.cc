@@ -350,7 +350,7 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
         }
         if (const char *e = getenv("AUDIOMOD_PV_CHAIN_WAVES")) { // tuning knob: upper bound of waves per workgroup
             const int v = atoi(e);
-            if (v >= 1 && v < wmax) wmax = v;
+            if (v >= 1 && v <= (d.fft.nc == 2048 ? 8 : 16)) wmax = v;
         }
         ChainArgs probe{};
         probe.AR = chain_AR;
@@ -764,6 +764,11 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
                 return e ? atoi(e) : -1;
             }();
             qa.high_prio = prio >= 0 ? prio : 1; // (measured without: no difference, 56.6 vs 56.4 ms per step)
+            static const int narrow = [] {
+                const char *e = getenv("AUDIOMOD_PV_SEQ_NARROW");
+                return e ? atoi(e) : 0;
+            }();
+            qa.narrow = narrow;
         }
         if (single_launch) fused.qa = qa;
         else side_stream(PV_K_SEQ, [&](hipStream_t s) { launch_seq(qa, s); });

@@ -79,6 +79,7 @@ struct MatchArgs {
 struct SeqArgs {
     int N, hs, HP, PKP, C, hop, TR, rows, Tn, s0;
     int high_prio; // s_setprio(3): win every issue arbitration (when the chain's result is what everybody waits for)
+    int narrow;    // three peaks per lane: a third of the waves per row (to share a CU with the fused kernel)
     double two_pi_hop;
     int64_t t0;
     const int32_t *phase_inc;

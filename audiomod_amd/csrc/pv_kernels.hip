@@ -707,6 +707,9 @@ __device__ __forceinline__ int region_of(const uint16_t *pk, int n, int i) {
     return lo;
 }
 
+// kK: peaks per lane in the fast loop (1: a lane per peak, six waves per row at 2048 points; 3: two waves per row --
+// a third of the wave slots and registers beside whatever shares the CU, at the price of a longer step)
+template <int kK = 1>
 __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *smem_raw) {
     float *srot0 = reinterpret_cast<float *>(smem_raw);          // [PKP]
     float *srot1 = srot0 + a.PKP;                                // [PKP]
@@ -726,7 +729,7 @@ __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *
 
     // the step's inputs (mode, peak count, this lane's peak record) do not depend on the recurrence: they are
     // fetched one step ahead so the global-load latency overlaps the previous step's princarg chain
-    const bool one_pass = a.PKP <= nt; // every peak has its own lane
+    const bool one_pass = a.PKP <= kK * nt; // every peak has its own lane (or one of a lane's kK slots)
     auto plane_of = [&](int tl) { return (int64_t)row * a.TR + ring_slot(a.s0, tl, a.TR); };
     // (one_pass: every peak has its own lane)
     // The header is wave-uniform, but it must come through the vector memory path: a scalar load shares its
@@ -736,14 +739,23 @@ __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *
     asm volatile("" : "+v"(vz));
     // unconditional (index clamped): a load inside an exec-masked branch gets its s_waitcnt at the end of
     // the branch, which would defeat the prefetch
-    const int rix = tid < a.PKP ? tid : a.PKP - 1;
+    int rixk[kK];
+#pragma unroll
+    for (int k = 0; k < kK; ++k) rixk[k] = tid + k * nt < a.PKP ? tid + k * nt : a.PKP - 1;
+    const int rix = rixk[0];
     // Prefetch ONE step ahead.  Measured alternatives (all slower alone on the GPU): queues 4 and 6 steps deep
     // (+15 %: the chain, not the load latency, bounds a step), always-clamped loads instead of the uniform
     // last-step branch (+13 %).
     auto ld_hdr = [&](int tl) -> uint32_t { return a.recs[plane_of(tl) * a.PKP + a.PKP - 1 + vz].p1r1; };
     auto ld_rec = [&](int tl) -> PeakRec { return a.recs[plane_of(tl) * a.PKP + rix]; };
+    auto ld_recs = [&](int tl, PeakRec (&q)[kK]) {
+#pragma unroll
+        for (int k = 0; k < kK; ++k) q[k] = a.recs[plane_of(tl) * a.PKP + rixk[k]];
+    };
     uint32_t h0 = ld_hdr(0);
-    PeakRec q0 = ld_rec(0);
+    PeakRec qk[kK];
+    ld_recs(0, qk);
+    (void)ld_rec;
 
     int tl = 0;
     while (tl < a.Tn) {
@@ -752,26 +764,36 @@ __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *
         // flight); the slow per-bin path lives outside this loop precisely to keep that count static.
         while (tl < a.Tn && (h0 & 3u) == (uint32_t)kModeLock && one_pass) {
             const int64_t plane = plane_of(tl);
-            const PeakRec r = q0;
+            PeakRec rk[kK];
+#pragma unroll
+            for (int k = 0; k < kK; ++k) rk[k] = qk[k];
             if (tl + 1 < a.Tn) { // uniform branch
                 h0 = ld_hdr(tl + 1);
-                q0 = ld_rec(tl + 1);
+                ld_recs(tl + 1, qk);
             } else {
                 h0 = 3u; // sentinel: leaves both loops
             }
             // Branch-free over the lanes: lanes beyond the peak count run on whatever their (clamped) record
             // slot holds and write slots nobody reads.
-            const uint32_t r1 = min(r.p1r1 >> 16, (uint32_t)(a.PKP - 1));
-            const uint32_t p1 = (r.p1r1 & 0xffffu) & (uint32_t)(hs - 1);
             // straight-line code (princarg_div has no rare-case branch): any branch inside this loop makes the
             // compiler fall back to vmcnt(0) at the joins, which exposes the store latency under load
-            const float po_lock = (float)princarg_small((double)(r.a1 + rprev[r1]));
-            const float po_full = spo[p1];
-            const float po = kind == 2 ? po_lock : (kind == 1 ? po_full : 0.f);
-            const float tgt = (float)princarg_div((double)(po + r.adv));
-            const float rt = (float)princarg_small((double)(tgt - r.a2));
-            rcur[rix] = rt;
-            a.rot[plane * a.PKP + rix] = rt;
+            float rtk[kK];
+#pragma unroll
+            for (int k = 0; k < kK; ++k) {
+                const PeakRec r = rk[k];
+                const uint32_t r1 = min(r.p1r1 >> 16, (uint32_t)(a.PKP - 1));
+                const uint32_t p1 = (r.p1r1 & 0xffffu) & (uint32_t)(hs - 1);
+                const float po_lock = (float)princarg_small((double)(r.a1 + rprev[r1]));
+                const float po_full = spo[p1];
+                const float po = kind == 2 ? po_lock : (kind == 1 ? po_full : 0.f);
+                const float tgt = (float)princarg_div((double)(po + r.adv));
+                rtk[k] = (float)princarg_small((double)(tgt - r.a2));
+            }
+#pragma unroll
+            for (int k = 0; k < kK; ++k) {
+                rcur[rixk[k]] = rtk[k];
+                a.rot[plane * a.PKP + rixk[k]] = rtk[k];
+            }
             kind = 2;
             float *tmp = rprev;
             rprev = rcur;
@@ -786,7 +808,7 @@ __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *
         const int mode = (int)(h0 & 3u), n = (int)(h0 >> 2);
         if (tl + 1 < a.Tn) {
             h0 = ld_hdr(tl + 1);
-            q0 = ld_rec(tl + 1);
+            ld_recs(tl + 1, qk);
         }
         if (mode == kModeLock) {
             for (int p = tid; p < n; p += nt) {
@@ -850,12 +872,12 @@ __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *
     (void)c;
 }
 
-__global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
+template <int kK> __global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // the chain is pure latency and may share the GPU with the overlap-add tiles of the previous chunk (second
     // HIP stream): let its few waves win every issue arbitration
     if (a.high_prio) __builtin_amdgcn_s_setprio(3);
-    seq_role(a, blockIdx.x, smem_raw);
+    seq_role<kK>(a, blockIdx.x, smem_raw);
 }
 
 int seq_threads(int PKP) {
@@ -867,11 +889,20 @@ int seq_threads(int PKP) {
 size_t seq_lds_bytes(const SeqArgs &a) { return sizeof(float) * ((size_t)2 * a.PKP + a.hs) + sizeof(uint16_t) * a.PKP; }
 
 void launch_seq(const SeqArgs &a, hipStream_t st) {
-    const int nt = seq_threads(a.PKP);
     const size_t lds = seq_lds_bytes(a);
-    static unsigned long long big = 0;
-    allow_big_lds_dev(pv_seq_kernel, big);
-    hipLaunchKernelGGL(pv_seq_kernel, dim3(a.rows), dim3(nt), lds, st, a);
+    static unsigned long long big1 = 0, big3 = 0;
+    if (a.narrow && a.PKP <= 3 * 1024) {
+        // three peaks per lane: a third of the waves (two per row at 2048 points), so that the kernel finds room on
+        // a CU beside the fused kernel's workgroup
+        int nt = ((a.PKP + 2) / 3 + 63) & ~63;
+        if (nt > 1024) nt = 1024;
+        allow_big_lds_dev(pv_seq_kernel<3>, big3);
+        hipLaunchKernelGGL(pv_seq_kernel<3>, dim3(a.rows), dim3(nt), lds, st, a);
+        return;
+    }
+    const int nt = seq_threads(a.PKP);
+    allow_big_lds_dev(pv_seq_kernel<1>, big1);
+    hipLaunchKernelGGL(pv_seq_kernel<1>, dim3(a.rows), dim3(nt), lds, st, a);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -2494,7 +2525,7 @@ template <int NC> __global__ __launch_bounds__(kStreamThreads) void pv_stream_ke
             match_wave_role(s.ma, i / Tn, i % Tn, smem_raw + (size_t)wave * match_wave_lds(s.ma.hs, s.ma.PKP));
         stage_handoff();
         for (int row = 0; row < rows; ++row) {
-            seq_role(s.qa, row, smem_raw);
+            seq_role<1>(s.qa, row, smem_raw);
             stage_handoff();
         }
     } else if (s.coremode == 0) {
