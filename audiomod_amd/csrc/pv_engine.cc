@@ -116,6 +116,8 @@ struct ChainBuilder {
     std::deque<Live> live; // frames that may still cover samples not yet finalised, oldest first
     bool any_upper_skip = false;
     int64_t launch_k0 = 0; // first output of the current launch (begin_launch)
+    std::vector<ChainSlice> launch_cs; // the current launch's slices, in order (end_launch turns them into run lists)
+    std::vector<int64_t> launch_P;
 
     ChainBuilder(const Derived &dd, int ar, int mask) : d(dd), AR(ar), smask(mask) {}
 
@@ -135,9 +137,9 @@ struct ChainBuilder {
         return acc;
     }
     // out_limit: outputs at or beyond it are not written (the CLI truncates to the input length).
-    void add(const SliceRec &r, int64_t out_limit, std::vector<ChainSlice> &cs, std::vector<float> &wden,
-             std::vector<float> &wden_hi) {
+    void add(const SliceRec &r, int64_t out_limit, std::vector<float> &wden, std::vector<float> &wden_hi) {
         ChainSlice c{};
+        c.tl = (int32_t)launch_cs.size();
         c.acc_pos = pmod(r.P, AR);
         c.str_pos = (int32_t)(r.P & (int64_t)smask);
         c.adv = r.adv;
@@ -163,18 +165,77 @@ struct ChainBuilder {
             c.k_off = (int32_t)(lo - launch_k0);
             c.kcnt = (int32_t)(hi - lo);
         }
-        cs.push_back(c);
+        launch_cs.push_back(c);
+        launch_P.push_back(r.P);
     }
     // the first output of the launch, relative to which k_off counts
     int64_t begin_launch(const SliceRec &first) {
         launch_k0 = first.K0;
+        launch_cs.clear();
+        launch_P.clear();
         return launch_k0;
+    }
+    // Ends the launch: its slices become the lists of up to `runs_wanted` runs (one workgroup each per row).  Run 0
+    // continues from the row's carried accumulator.  A later run starts from an empty one and first re-adds the
+    // frames before its range whose tails reach into it -- every frame j with P_j + N > P_start, copied in front of
+    // its list with flag bit 1 (rebuilt, not emitted): from its first own sample on, its accumulator then holds the
+    // same sums in the same order as the sequential walk.  The number of runs is cut down until that warm-up is at
+    // most half a run (and falls back to one run where it would reach before the launch).
+    // Appends the lists to `cs` and runs + 1 offsets (relative to the launch's first entry in `cs`) to `run_off`;
+    // returns the number of runs.
+    int end_launch(int runs_wanted, std::vector<ChainSlice> &cs, std::vector<int32_t> &run_off) {
+        const int Tn = (int)launch_cs.size();
+        int R = runs_wanted < 1 ? 1 : runs_wanted;
+        std::vector<int> start, warm;
+        for (; R > 1; R = R / 2) {
+            const int L = (Tn + R - 1) / R;
+            bool ok = L >= 2;
+            start.clear();
+            warm.clear();
+            for (int r = 1; ok && r < R; ++r) {
+                const int a = r * L;
+                if (a >= Tn) {
+                    ok = false;
+                    break;
+                }
+                int w = a;
+                while (w > 0 && launch_P[(size_t)(w - 1)] + d.N > launch_P[(size_t)a]) --w;
+                if (w == 0 && launch_P[0] + d.N > launch_P[(size_t)a]) ok = false; // would need frames of the launch before
+                if (2 * (a - w) > L) ok = false;
+                start.push_back(a);
+                warm.push_back(w);
+            }
+            if (ok) break;
+        }
+        const size_t base = cs.size();
+        if (R <= 1) {
+            run_off.push_back(0);
+            cs.insert(cs.end(), launch_cs.begin(), launch_cs.end());
+            run_off.push_back((int32_t)(cs.size() - base));
+            return 1;
+        }
+        const int L = (Tn + R - 1) / R;
+        for (int r = 0; r < R; ++r) {
+            run_off.push_back((int32_t)(cs.size() - base));
+            const int a = r * L, b = (r + 1) * L < Tn ? (r + 1) * L : Tn;
+            if (r > 0)
+                for (int j = warm[(size_t)(r - 1)]; j < a; ++j) {
+                    ChainSlice w = launch_cs[(size_t)j];
+                    w.flags |= 2;
+                    cs.push_back(w);
+                }
+            for (int j = a; j < b; ++j) cs.push_back(launch_cs[(size_t)j]);
+        }
+        run_off.push_back((int32_t)(cs.size() - base));
+        return R;
     }
 };
 
 // what one launch of the fused synthesis + overlap-add kernel needs from the host plan
 struct ChainLaunch {
-    const ChainSlice *slices; // [Tn] device
+    const ChainSlice *slices; // the launch's run lists (device)
+    const int32_t *run_off;   // [runs + 1]
+    int runs;
     const float *wden, *wden_hi;
     float *out;               // the row-0 address of the launch's first output
     // resampling configurations: the second kernel's tiles for the outputs this launch completes
@@ -214,11 +275,15 @@ struct Core {
     // their images are carried here between launches.  On by default (AUDIOMOD_PV_FUSED=0 selects the frame ring +
     // tile kernel instead, which cannot represent dropped slices).
     bool use_chain = false;
-    // The fused kernel runs one workgroup per row: below ~3/4 of the chip's 256 CUs in rows it leaves CUs idle and the
-    // tile path (frames through HBM, thousands of small workgroups) is faster.  A batch takes the fused path when it
-    // has the rows, or when its plan contains dropped slices (only the fused path's accumulator can represent
-    // them); the streaming engine always does (it must follow whatever the caller's call sizes lead to).
+    // The fused kernel runs one workgroup per (row, run); a batch with fewer than 256 rows splits each row's slices
+    // of a launch into runs (ChainBuilder::end_launch) to fill the chip.  Very small batches stay on the tile path
+    // (frames through HBM, thousands of small workgroups) unless their plan contains dropped slices (only the fused
+    // path's accumulator can represent them) or AUDIOMOD_PV_FUSED=2 asks for it; the streaming engine always takes
+    // the fused path (it must follow whatever the caller's call sizes lead to).
     bool chain_required = false; // set before init()
+    // (measured, 128 / 64 / 32 rows: fused + runs 31.9 / 20.0 / 12.2 ms per step against the tile path's 31.2 / 17.2 /
+    // 12.2 -- below a full chip's worth of rows the rotation chain's serial latency dominates either way, and the
+    // tile path's kernels need no warm-up)
     static constexpr int kChainMinRows = 192;
     bool three_stage = false; // pipelined batch path: resampling of chunk i-2 between the front of i and the fused kernel of i-1
     int chain_AR = 0, chain_smask = 0, chain_waves = 0;
@@ -859,6 +924,8 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
             ca.diag = diag;
         }
         ca.slices = chain->slices;
+        ca.run_off = chain->run_off;
+        ca.runs = chain->runs;
         ca.wden = chain->wden;
         ca.wden_hi = chain->wden_hi;
         ca.st_acc = st_acc.p;
@@ -1004,8 +1071,11 @@ struct pv_batch {
         int tile_begin, ntiles;
         int64_t k0; // fused path: first output of the chunk
         int res_begin, res_ntiles; // ... and its tiles of the resampling kernel
+        int64_t cs_begin;          // ... its run lists in d_cs
+        int run_begin, runs;       // ... and their offsets in d_run_off
     };
-    DevBuf<ChainSlice> d_cs; // fused path: one entry per slice of the plan
+    DevBuf<ChainSlice> d_cs; // fused path: the run lists of every chunk
+    DevBuf<int32_t> d_run_off;
     DevBuf<float> d_wden, d_wden_hi;
     DevBuf<ResTile> d_res_tiles;
     DevBuf<uint2> d_res_otab;
@@ -1197,6 +1267,7 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
     std::vector<OlaTile> tiles;
     std::vector<float> wacc;
     std::vector<ChainSlice> cs;
+    std::vector<int32_t> run_off;
     std::vector<float> wden, wden_hi;
     std::vector<ResTile> res_tiles;
     std::vector<uint2> res_otab;
@@ -1207,6 +1278,9 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
         ch.Tn = (int)((T - t0) < Tc ? (T - t0) : Tc);
         ch.k0 = 0;
         ch.res_begin = ch.res_ntiles = 0;
+        ch.cs_begin = 0;
+        ch.run_begin = 0;
+        ch.runs = 1;
         const int64_t t1 = t0 + ch.Tn;
         int64_t ka = sl[(size_t)t0].K0;
         int64_t kb = sl[(size_t)(t1 - 1)].K0 + sl[(size_t)(t1 - 1)].cnt;
@@ -1215,7 +1289,13 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
         ch.tile_begin = (int)tiles.size();
         if (c.use_chain) {
             ch.k0 = cb.begin_launch(sl[(size_t)t0]);
-            for (int64_t t = t0; t < t1; ++t) cb.add(sl[(size_t)t], b->plan.out_frames, cs, wden, wden_hi);
+            for (int64_t t = t0; t < t1; ++t) cb.add(sl[(size_t)t], b->plan.out_frames, wden, wden_hi);
+            // one workgroup per row leaves CUs idle below 256 rows: split the rows' slices into runs
+            int runs_wanted = (256 + c.rows - 1) / c.rows;
+            if (const char *e = getenv("AUDIOMOD_PV_CHAIN_RUNS")) runs_wanted = atoi(e);
+            ch.cs_begin = (int64_t)cs.size();
+            ch.run_begin = (int)run_off.size();
+            ch.runs = cb.end_launch(runs_wanted > 32 ? 32 : runs_wanted, cs, run_off);
             if (c.d.resample && kb > ka) {
                 ch.res_begin = (int)res_tiles.size();
                 c.build_res_tiles(ka, kb, res_tiles, res_otab);
@@ -1237,6 +1317,7 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
         while (wden.size() & 3) wden.push_back(1.f), wden_hi.push_back(1.f);
         for (int i = 0; i < 4; ++i) wden.push_back(1.f), wden_hi.push_back(1.f);
         if ((st = b->d_cs.upload(cs)) != PV_OK) return st;
+        if ((st = b->d_run_off.upload(run_off)) != PV_OK) return st;
         if ((st = b->d_wden.upload(wden)) != PV_OK) return st;
         if (cb.any_upper_skip) {
             if ((st = b->d_wden_hi.upload(wden_hi)) != PV_OK) return st;
@@ -1357,7 +1438,9 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
         const auto &ch = b->chunks[ci];
         ChainLaunch cl{};
         if (c.use_chain) {
-            cl.slices = b->d_cs.p + ch.t0;
+            cl.slices = b->d_cs.p + ch.cs_begin;
+            cl.run_off = b->d_run_off.p + ch.run_begin;
+            cl.runs = ch.runs;
             cl.wden = b->d_wden.p;
             cl.wden_hi = b->d_wden_hi.p ? b->d_wden_hi.p : b->d_wden.p;
             cl.res_tiles = b->d_res_tiles.p + ch.res_begin;
@@ -1612,7 +1695,9 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         if (c.use_chain) {
             e->chain->begin_launch(first);
             for (int64_t t = ta; t < tb; ++t)
-                e->chain->add(e->recent[(size_t)(t - e->t_base)], INT64_MAX, cs, wden, wden_hi);
+                e->chain->add(e->recent[(size_t)(t - e->t_base)], INT64_MAX, wden, wden_hi);
+            std::vector<int32_t> ro;
+            e->chain->end_launch(1, cs, ro); // a call's few slices: one run
             if (c.d.resample && kb > ka) c.build_res_tiles(ka, kb, res_tiles, res_otab);
             while (wden.size() & 3) wden.push_back(1.f), wden_hi.push_back(1.f);
             for (int i = 0; i < 4; ++i) wden.push_back(1.f), wden_hi.push_back(1.f);
@@ -1623,7 +1708,7 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         auto pad16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
         const size_t nP = c.use_chain ? 0 : (size_t)(tb - e->t_base);
         const bool hi = c.use_chain && e->chain->any_upper_skip;
-        const size_t o_pinc = 0, o_a = pad16((size_t)Tn * 4);
+        const size_t o_pinc = 0, o_ro = pad16((size_t)Tn * 4), o_a = o_ro + 16; // (o_ro: the run offsets {0, Tn})
         const size_t o_b = o_a + (c.use_chain ? pad16(cs.size() * sizeof(ChainSlice)) : pad16(nP * 8));
         const size_t o_c = o_b + (c.use_chain ? pad16(wden.size() * 4) : pad16(tiles.size() * sizeof(OlaTile)));
         const size_t o_d = o_c + (c.use_chain ? (hi ? pad16(wden_hi.size() * 4) : 0) : pad16(wacc.size() * 4));
@@ -1633,6 +1718,10 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         char *hd = e->h_desc.p;
         int32_t *h_pinc = reinterpret_cast<int32_t *>(hd + o_pinc);
         for (int i = 0; i < Tn; ++i) h_pinc[i] = e->recent[(size_t)(ta + i - e->t_base)].phase_inc;
+        {
+            int32_t *h_ro = reinterpret_cast<int32_t *>(hd + o_ro);
+            h_ro[0] = 0, h_ro[1] = (int32_t)cs.size(), h_ro[2] = h_ro[3] = 0;
+        }
         if (c.use_chain) {
             memcpy(hd + o_a, cs.data(), cs.size() * sizeof(ChainSlice));
             memcpy(hd + o_b, wden.data(), wden.size() * 4);
@@ -1670,6 +1759,8 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         ChainLaunch cl{};
         if (c.use_chain) {
             cl.slices = reinterpret_cast<const ChainSlice *>(e->d_desc.p + o_a);
+            cl.run_off = reinterpret_cast<const int32_t *>(e->d_desc.p + o_ro);
+            cl.runs = 1;
             cl.wden = reinterpret_cast<const float *>(e->d_desc.p + o_b);
             cl.wden_hi = hi ? reinterpret_cast<const float *>(e->d_desc.p + o_c) : cl.wden;
             cl.res_tiles = reinterpret_cast<const ResTile *>(e->d_desc.p + o_d);

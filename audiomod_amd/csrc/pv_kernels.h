@@ -204,8 +204,9 @@ struct ChainSlice {
     int32_t k_off;    // not resampling: first output (= finalised sample) of the slice, relative to the launch's
     int32_t kcnt;     // ... and how many of its samples are outputs (the CLI truncates the last ones)
     int32_t flags;    // bit 0: channels > 0 do not add this frame (CONSTANT-mode overrun: processOneSliceConstant
-                      // returns after channel 0, phasevocoderprocess.cc:139-150)
-    int32_t pad;
+                      // returns after channel 0, phasevocoderprocess.cc:139-150); bit 1: warm-up slice of a later
+                      // run -- added and finalised like any other, but its samples are not emitted
+    int32_t tl;       // which slice of the launch this is (planes, frame ring)
 };
 
 struct ChainArgs {
@@ -215,7 +216,11 @@ struct ChainArgs {
     int waves;  // W: waves per workgroup (= slices of a row in flight)
     int diag;   // measurement builds only (AUDIOMOD_PV_CHAIN_DIAG, results are wrong when set): bit 2 no waiting for
                 // the turn, bit 3 no synthesis
-    const ChainSlice *slices; // [Tn]
+    // A row's slices are processed by `runs` workgroups: run r walks slices[run_off[r] .. run_off[r + 1]), a list
+    // that begins with the frames before its range whose tails reach into it (flag bit 1: rebuilt, not emitted)
+    int runs;
+    const int32_t *run_off;   // [runs + 1]
+    const ChainSlice *slices; // run lists, concatenated
     const float *wden;        // denominators, indexed wden_off + quad-relative sample
     const float *wden_hi;     // ... for channels > 0 (differs from wden only after a CONSTANT-mode overrun)
     float *st_acc;            // [rows][AR] ring image carried between launches

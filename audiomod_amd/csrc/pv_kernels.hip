@@ -1995,15 +1995,19 @@ __host__ __device__ inline size_t chain_shared_bytes(const ChainArgs &c) {
 }
 
 // ring images and coefficient table in, before the first slice (whole workgroup)
-__device__ __forceinline__ void chain_prologue(const ChainArgs &c, const ChainLds &l, int row) {
+// (first run of a row: the carried accumulator; later runs start from zeros and rebuild what reaches into their range
+// by re-adding the frames before it, ChainSlice flag bit 1)
+__device__ __forceinline__ void chain_prologue(const ChainArgs &c, const ChainLds &l, int row, bool first_run = true) {
     const int nt = blockDim.x, tid = threadIdx.x;
     const float4 *sa = reinterpret_cast<const float4 *>(c.st_acc + (int64_t)row * c.AR);
-    for (int i = tid; i < c.AR / 4; i += nt) reinterpret_cast<float4 *>(l.acc)[i] = sa[i];
+    for (int i = tid; i < c.AR / 4; i += nt)
+        reinterpret_cast<float4 *>(l.acc)[i] = first_run ? sa[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid == 0) *l.turn = 0;
     __syncthreads();
 }
-__device__ __forceinline__ void chain_epilogue(const ChainArgs &c, const ChainLds &l, int row) {
-    __syncthreads(); // every wave has passed its last turn and finished reading the stream ring
+__device__ __forceinline__ void chain_epilogue(const ChainArgs &c, const ChainLds &l, int row, bool last_run = true) {
+    __syncthreads(); // every wave has passed its last turn
+    if (!last_run) return; // only the run that ends the launch holds the row's true accumulator
     const int nt = blockDim.x, tid = threadIdx.x;
     float4 *sa = reinterpret_cast<float4 *>(c.st_acc + (int64_t)row * c.AR);
     for (int i = tid; i < c.AR / 4; i += nt) sa[i] = reinterpret_cast<const float4 *>(l.acc)[i];
@@ -2105,7 +2109,9 @@ __device__ __forceinline__ void chain_finish_slice(const ChainArgs &c_in, const 
         int ai = sl.acc_pos + i;
         return ai >= c.AR ? ai - c.AR : ai;
     };
+    const bool quiet = (sl.flags & 2) != 0; // a warm-up slice of a later run: its samples belong to the run before
     auto emit = [&](int i, float y) {
+        if (quiet) return;
         if (c.resample) {
             stream[(uint32_t)(sl.str_pos + i) & (uint32_t)c.smask] = y;
         } else if (i < sl.kcnt) {
@@ -2220,8 +2226,9 @@ __device__ __forceinline__ void chain_slice_tail(const ChainArgs &c_in, const Ch
     // ---- after the turn: normalise the finalised samples and append them to the stream (or emit them)
     float *__restrict__ out = c.out + (int64_t)row * c.out_stride_row + sl.k_off;
     float *__restrict__ stream = c.stream + (int64_t)row * ((int64_t)c.smask + 1);
+    const bool quiet = (sl.flags & 2) != 0; // a warm-up slice of a later run: its samples belong to the run before
     auto emit = [&](int sidx, float y) { // sidx: sample index relative to P_t
-        if (sidx < 0 || sidx >= sl.adv) return;
+        if (quiet || sidx < 0 || sidx >= sl.adv) return;
         if (c.resample) {
             stream[(uint32_t)(sl.str_pos + sidx) & (uint32_t)c.smask] = y;
         } else if (sidx < sl.kcnt) {
@@ -2254,19 +2261,23 @@ __global__ __launch_bounds__(NC == 1024 ? ((kPlainCore < 0 || kPlainCore == 3) ?
     using W = WF<NC>;
     constexpr int N = 2 * NC, hs = NC, NQ = N / 4, NP = NQ / 64;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int row = blockIdx.x;
+    const int row = blockIdx.x, run = blockIdx.y;
+    // a row's slices of the launch are split into gridDim.y runs, one workgroup each (entry i of a run's list is its
+    // i-th slice in order, warm-up slices first; ChainSlice::tl says which slice of the launch it is)
+    const int i_begin = c.run_off[run], i_count = c.run_off[run + 1] - i_begin;
     cf *wlds = reinterpret_cast<cf *>(smem_raw) + wave * W::LDS_CF;
     const ChainLds l = chain_carve(c, smem_raw + (size_t)c.waves * W::LDS_CF * sizeof(cf));
-    chain_prologue(c, l, row);
+    chain_prologue(c, l, row, run == 0);
     const float *__restrict__ w = s.tb.window;
     const bool upper = (row % c.C) > 0;
     const int lane0 = lane;
-    for (int tl = wave; tl < c.Tn; tl += c.waves) {
+    for (int i = wave; i < i_count; i += c.waves) {
         // the lane id, made opaque once per iteration: everything derived from it is recomputed per slice instead of
         // being hoisted out of the loop and held in registers (which spilled ~100 VGPRs)
         int lane = lane0;
         asm volatile("" : "+v"(lane));
-        const ChainSlice sl = c.slices[tl];
+        const ChainSlice sl = c.slices[i_begin + i];
+        const int tl = sl.tl;
         const bool skip = (sl.flags & 1) && upper; // wave-uniform
         float4 A[NP];
         if (!skip) {
@@ -2282,12 +2293,12 @@ __global__ __launch_bounds__(NC == 1024 ? ((kPlainCore < 0 || kPlainCore == 3) ?
             }
         }
         const int r = sl.acc_pos & 3; // wave-uniform
-        if (r == 0) chain_slice_tail<0, NP, kRes>(c, l, sl, A, skip, row, tl, lane);
-        else if (r == 1) chain_slice_tail<1, NP, kRes>(c, l, sl, A, skip, row, tl, lane);
-        else if (r == 2) chain_slice_tail<2, NP, kRes>(c, l, sl, A, skip, row, tl, lane);
-        else chain_slice_tail<3, NP, kRes>(c, l, sl, A, skip, row, tl, lane);
+        if (r == 0) chain_slice_tail<0, NP, kRes>(c, l, sl, A, skip, row, i, lane);
+        else if (r == 1) chain_slice_tail<1, NP, kRes>(c, l, sl, A, skip, row, i, lane);
+        else if (r == 2) chain_slice_tail<2, NP, kRes>(c, l, sl, A, skip, row, i, lane);
+        else chain_slice_tail<3, NP, kRes>(c, l, sl, A, skip, row, i, lane);
     }
-    chain_epilogue(c, l, row);
+    chain_epilogue(c, l, row, run == (int)gridDim.y - 1);
 }
 
 // Any FFT size: the synthesis kernel has written the windowed frames to the HBM frame ring; the chain takes them
@@ -2295,14 +2306,16 @@ __global__ __launch_bounds__(NC == 1024 ? ((kPlainCore < 0 || kPlainCore == 3) ?
 template <int kRes> __global__ __launch_bounds__(1024) void pv_frames_chain_kernel(const ChainArgs c) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int row = blockIdx.x;
+    const int row = blockIdx.x, run = blockIdx.y;
+    const int i_begin = c.run_off[run], i_count = c.run_off[run + 1] - i_begin;
     const ChainLds l = chain_carve(c, smem_raw);
-    chain_prologue(c, l, row);
+    chain_prologue(c, l, row, run == 0);
     const int NQ = c.N >> 2;
     const int groups = (NQ + 511) >> 9;
     const bool upper = (row % c.C) > 0;
-    for (int tl = wave; tl < c.Tn; tl += c.waves) {
-        const ChainSlice sl = c.slices[tl];
+    for (int i = wave; i < i_count; i += c.waves) {
+        const ChainSlice sl = c.slices[i_begin + i];
+        const int tl = sl.tl;
         const bool skip = (sl.flags & 1) && upper;
         ChainPrefetch pf;
         chain_prefetch(c, sl, row, lane, pf);
@@ -2318,7 +2331,7 @@ template <int kRes> __global__ __launch_bounds__(1024) void pv_frames_chain_kern
         };
         float4 A[8];
         load_group(0, A);
-        chain_wait_turn(l.turn, tl);
+        chain_wait_turn(l.turn, i);
         if (!skip) {
             float4 prevR = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int g = 0; g < groups; ++g) {
@@ -2327,9 +2340,9 @@ template <int kRes> __global__ __launch_bounds__(1024) void pv_frames_chain_kern
             }
             wave_sync();
         }
-        chain_finish_slice<kRes>(c, l, sl, pf, row, tl, lane);
+        chain_finish_slice<kRes>(c, l, sl, pf, row, i, lane);
     }
-    chain_epilogue(c, l, row);
+    chain_epilogue(c, l, row, run == (int)gridDim.y - 1);
 }
 
 size_t chain_lds_bytes(const ChainArgs &a, int nc_wave) {
@@ -2340,7 +2353,7 @@ size_t chain_lds_bytes(const ChainArgs &a, int nc_wave) {
 
 template <int NC, int kPlainCore> static void launch_synth_chain_res(const SynthArgs &s, const ChainArgs &c, hipStream_t st) {
     const size_t lds = chain_lds_bytes(c, NC);
-    const dim3 grid(c.rows), block(64 * c.waves);
+    const dim3 grid(c.rows, c.runs), block(64 * c.waves);
     static unsigned long long m0 = 0, m1 = 0;
     if (!c.resample) {
         allow_big_lds_dev(pv_synth_chain_kernel<NC, kPlainCore, 0>, m0);
@@ -2372,7 +2385,7 @@ void launch_synth_chain(const SynthArgs &s, const ChainArgs &c, hipStream_t st) 
 
 void launch_frames_chain(const ChainArgs &c, hipStream_t st) {
     const size_t lds = chain_lds_bytes(c, 0);
-    const dim3 grid(c.rows), block(64 * c.waves);
+    const dim3 grid(c.rows, c.runs), block(64 * c.waves);
     static unsigned long long m0 = 0, m1 = 0;
     if (!c.resample) {
         allow_big_lds_dev(pv_frames_chain_kernel<0>, m0);
