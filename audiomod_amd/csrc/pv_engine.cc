@@ -248,6 +248,7 @@ struct ChainLaunch {
     // finished before this launch's fused kernel may overwrite the stream ring (two launches back).
     hipStream_t res_stream;
     hipEvent_t ev_fused, ev_res, ev_ring_free;
+    bool late_chain; // three-stage order: the rotation chain is handed over by a separate call (part 5)
 };
 
 struct Core {
@@ -717,8 +718,12 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
                         hipEvent_t ev_chain, bool single_launch, const ChainLaunch *chain) const {
     // part 3 / 4: the back of a chunk in two pieces (fused path: 3 = everything up to the fused synthesis +
     // overlap-add kernel, 4 = the resampling kernel), for the three-stage order of pv_batch_run
-    const bool only_resample = part == 4, no_resample = part == 3;
+    // part 5: only the rotation chain's hand-over to the second stream (for the order in which the chain starts behind
+    // the previous chunk's fused kernel rather than right behind its own match kernel: ChainLaunch::late_chain)
+    const bool only_resample = part == 4, no_resample = part == 3, only_chain = part == 5;
+    const bool defer_chain = part == 1 && chain && chain->late_chain;
     if (part == 3 || part == 4) part = 2;
+    if (part == 5) part = 1;
     const bool front = part != 2, back = part != 1;
     StreamArgs fused{};
     const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder;
@@ -729,6 +734,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     // the phase stage's latency-bound kernel: on `st` (part 0), or handed to the second stream after what the
     // main stream has launched so far (part 1) and waited for before what follows (part 2)
     auto side_stream = [&](int k, auto &&launch_on) {
+        if (defer_chain) return;
         if (part == 1) {
             (void)hipEventRecord(ev_match, st);
             (void)hipStreamWaitEvent(st_chain, ev_match, 0);
@@ -760,10 +766,10 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     aa.phase = phase.p;
     aa.peaks = peaks.p;
     aa.npk = npk.p;
-    if (front) rec(2 * PV_K_ANALYZE);
+    if (front && !only_chain) rec(2 * PV_K_ANALYZE);
     if (single_launch) fused.aa = aa;
-    else if (front) launch_analyze(aa, st);
-    if (front && d.vocoder && carrier) {
+    else if (front && !only_chain) launch_analyze(aa, st);
+    if (front && !only_chain && d.vocoder && carrier) {
         // the carrier is one more (data-independent) row: same analysis, its own planes
         AnalyzeArgs ca = aa;
         ca.ia = *carrier;
@@ -773,7 +779,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ca.phase = cphase.p;
         launch_analyze(ca, st);
     }
-    if (front) rec(2 * PV_K_ANALYZE + 1);
+    if (front && !only_chain) rec(2 * PV_K_ANALYZE + 1);
 
     if (cm == 1) {
         MatchArgs ma{};
@@ -795,10 +801,10 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ma.npk = npk.p;
         ma.recs = recs.p;
         ma.modes = modes.p;
-        if (front) rec(2 * PV_K_MATCH);
+        if (front && !only_chain) rec(2 * PV_K_MATCH);
         if (single_launch) fused.ma = ma;
-        else if (front) launch_match(ma, st);
-        if (front) rec(2 * PV_K_MATCH + 1);
+        else if (front && !only_chain) launch_match(ma, st);
+        if (front && !only_chain) rec(2 * PV_K_MATCH + 1);
         SeqArgs qa{};
         qa.N = d.N;
         qa.hs = d.hs;
@@ -1434,6 +1440,12 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
         b->ev_chunk.push_back((int)ci);
         return ev;
     };
+    static const bool late_env = [] {
+        const char *e = getenv("AUDIOMOD_PV_LATE_CHAIN");
+        return e && atoi(e) != 0;
+    }();
+    const bool late = late_env && b->chain_stream != nullptr && c.use_chain && c.d.resample && c.wave_fft() &&
+                      b->res_stream == nullptr && c.three_stage;
     auto launch = [&](size_t ci, hipEvent_t *ev, int part) {
         const auto &ch = b->chunks[ci];
         ChainLaunch cl{};
@@ -1450,6 +1462,7 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
             cl.ev_fused = b->ev_fused[ci & 3];
             cl.ev_res = b->ev_res[ci & 3];
             cl.ev_ring_free = ci >= 2 ? b->ev_res[(ci - 2) & 3] : nullptr;
+            cl.late_chain = late;
             cl.out = d_out + ch.k0;
         }
         c.launch_chunk(ia, ch.t0, ch.Tn, b->d_pinc.p + ch.t0, b->d_tiles.p + ch.tile_begin, ch.ntiles, b->d_P.p,
@@ -1473,6 +1486,7 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
             if (three) {
                 if (ci > 1) launch(ci - 2, evs[ci - 2], 4);
                 if (ci > 0) launch(ci - 1, evs[ci - 1], 3);
+                if (late) launch(ci, evs[ci], 5); // the chain of chunk i starts behind the fused kernel of chunk i-1
             } else if (ci > 0) {
                 launch(ci - 1, evs[ci - 1], 2);
             }
