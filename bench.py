@@ -81,6 +81,9 @@ def cpu_baseline(seconds=480, all_cores_seconds=240):
                 ok = all(p.wait() == 0 for p in ps)
                 dta = time.perf_counter() - t0
                 if ok:
+                    # (also as flat fields, for readers that keep only scalars of this object)
+                    res["all_cores_value"] = round(ncpu * fa * 2 / dta / 1e6, 3)
+                    res["all_cores_count"] = ncpu
                     res["all_cores"] = {"cores": ncpu, "value": round(ncpu * fa * 2 / dta / 1e6, 3),
                                         "x_realtime": round(ncpu * fa / 48000 / dta, 1),
                                         "sample": f"{ncpu} independent stereo streams x {fa // 48000} s side by side, "
