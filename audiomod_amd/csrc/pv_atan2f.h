@@ -133,3 +133,116 @@ PV_AT_HD float pv_atan2f_fd(const float y, const float x) {
     if (ix > 0x7f800000 || iy > 0x7f800000) r = x + y;                    // NaN
     return r;
 }
+
+// --------------------------------------------------------------------------------------------------------------
+// Table-driven form of the finite-argument variant (round 2): the same operations on the same values, with the
+// interval of s_atanf.c's argument reduction looked up instead of selected.  The reduction of every interval is
+//     t = (a q + b) / (c q + a)     with (a, b, c) = (1, 0, 0)  (2, -1, 1)  (1, -1, 1)  (1, -1.5, 1.5)  (0, -1, 1)
+// -- the reference's q, (2q - 1) / (2 + q), (q - 1) / (q + 1), (q - 1.5) / (1 + 1.5 q), -1 / q: a q is exact, so
+// a q + b rounds once like the reference's numerator; c q rounds only for c = 1.5, where the reference rounds too --
+// and the result hi - ((t (s1 + s2) - lo) - t), which for the interval that is not reduced (hi = lo = 0) is
+// t - t (s1 + s2) as in the reference (rounding is symmetric in sign).  All four thresholds are multiples of 2^18 in
+// the float's bit pattern, so bits 18..30 of q, offset and clamped to [0, 80], index an 81-byte map to the row.  A
+// tiny q needs no case of its own (t - t (s1 + s2) rounds to t = q below 2^-12), the reference's z = 0 for
+// |y / x| < 2^-60 neither (q - pi_lo rounds to -pi_lo), and a quotient of 2^25 and above -- which is where its
+// |y / x| > 2^60 case, an infinite quotient (x = 0) and 0 / 0 end up -- takes atanf's constant, which equals
+// pi_o_2 + 0.5 pi_lo.  tests/native/host_atan2f.cc sweeps this form against atan2f() with the others.
+// The blob (five 32-byte rows, then the byte map) is 256 bytes; the kernels keep a copy in LDS.
+// --------------------------------------------------------------------------------------------------------------
+#define PV_ATAN_BLOB_WORDS 64
+#define PV_ATAN_MAP_OFFSET 160
+#define PV_ATAN_KEY_BIAS 0xFB7 // (0x3ee00000 >> 18) - 1
+#if defined(__cplusplus)
+constexpr uint32_t pv_cf2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+constexpr uint32_t pv_atan_row_of_key(int k) { return 32u * ((k >= 1) + (k >= 21) + (k >= 47) + (k >= 80)); }
+constexpr uint32_t pv_atan_blob_word(int i) {
+    constexpr float rows[5][8] = {
+        {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0, 0, 0},
+        {2.0f, -1.0f, 1.0f, 4.6364760399e-01f, 5.0121582440e-09f, 0, 0, 0},
+        {1.0f, -1.0f, 1.0f, 7.8539812565e-01f, 3.7748947079e-08f, 0, 0, 0},
+        {1.0f, -1.5f, 1.5f, 9.8279368877e-01f, 3.4473217170e-08f, 0, 0, 0},
+        {0.0f, -1.0f, 1.0f, 1.5707962513e+00f, 7.5497894159e-08f, 0, 0, 0},
+    };
+    if (i < 40) return pv_cf2u(rows[i / 8][i % 8]);
+    uint32_t w = 0;
+    for (int b = 0; b < 4; ++b) {
+        const int k = 4 * (i - 40) + b;
+        w |= pv_atan_row_of_key(k > 80 ? 80 : k) << (8 * b);
+    }
+    return w;
+}
+struct PvAtanBlob {
+    uint32_t w[PV_ATAN_BLOB_WORDS];
+};
+constexpr PvAtanBlob pv_atan_make_blob() {
+    PvAtanBlob b{};
+    for (int i = 0; i < PV_ATAN_BLOB_WORDS; ++i) b.w[i] = pv_atan_blob_word(i);
+    return b;
+}
+
+// sqrtf(a) for a normal a in [2^-96, 2^127): the hardware square root (1 ulp) stepped to the correctly rounded
+// neighbour by the signs of the two exact residuals a - s (s -+ 1 ulp) -- the compiler's own expansion of sqrtf
+// without the input scaling and the zero / infinity pass-through that this range does not need.  Host: sqrtf.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float pv_sqrt_safe(const float a) {
+    const float s = __builtin_amdgcn_sqrtf(a);
+    const float sm = pv_u2f(pv_f2u(s) - 1u), sp = pv_u2f(pv_f2u(s) + 1u);
+    const float em = __builtin_fmaf(-sm, s, a), ep = __builtin_fmaf(-sp, s, a);
+    float r = em <= 0.0f ? sm : s;
+    r = ep > 0.0f ? sp : r;
+    return r;
+}
+#else
+PV_AT_HD float pv_sqrt_safe(const float a) { return __builtin_sqrtf(a); }
+#endif
+
+// `blob`: the 256 bytes above (16-byte aligned; in LDS on the device).  SAFE: the caller has checked that both
+// operands are normal with magnitudes in [2^-48, 2^63) -- y / x then goes through the short division, and the
+// zero cases of the reference cannot occur.
+template <bool SAFE> PV_AT_HD float pv_atan2f_fd_tab(const float y, const float x, const unsigned char *blob) {
+    const float pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    // (x = 0: the short division gives NaN where the IEEE one gives infinity -- both take the constant below)
+    const float quot = SAFE ? pv_div_safe(y, x) : y / x;
+    const uint32_t uq = pv_f2u(quot);
+    int key = (int)((uq >> 18) & 0x1fffu) - PV_ATAN_KEY_BIAS;
+    key = key < 0 ? 0 : (key > 80 ? 80 : key);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (LDS addresses as integers: the table's offset folds into the instructions' immediate field)
+    typedef __attribute__((address_space(3))) const unsigned char lds_u8;
+    typedef __attribute__((address_space(3))) const float4 lds_f4;
+    typedef __attribute__((address_space(3))) const float lds_f;
+    const uint32_t base = (uint32_t)(uintptr_t)blob; // the caller passes the table's LDS address as a number
+    const uint32_t off = *(lds_u8 *)(uintptr_t)(base + PV_ATAN_MAP_OFFSET + (uint32_t)key);
+    const float4 abch = *(lds_f4 *)(uintptr_t)(base + off);
+    const float a = abch.x, b = abch.y, c = abch.z, hi = abch.w;
+    const float lo = *(lds_f *)(uintptr_t)(base + off + 16u);
+#else
+    const uint32_t off = blob[PV_ATAN_MAP_OFFSET + key];
+    const float *row = reinterpret_cast<const float *>(blob + off);
+    const float a = row[0], b = row[1], c = row[2], hi = row[3];
+    const float lo = row[4];
+#endif
+    const float q = pv_u2f(uq & 0x7fffffffu);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float num = __builtin_fmaf(a, q, b); // a q is exact: one rounding either way
+#else
+    const float num = a * q + b;
+#endif
+    const float cq = c * q;
+    const float den = cq + a;
+    const float t = pv_div_safe(num, den);
+    const float z = t * t;
+    const float w = z * z;
+    const float s1 = z * (3.3333334327e-01f + w * (1.4285714924e-01f + w * (9.0908870101e-02f + w * (6.6610731184e-02f +
+                          w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
+    const float s2 = w * (-2.0000000298e-01f + w * (-1.1111110449e-01f + w * (-7.6918758452e-02f +
+                          w * (-5.8335702866e-02f + w * -3.6531571299e-02f))));
+    float at = hi - ((t * (s1 + s2) - lo) - t);
+    if (!(q < 0x1p25f)) at = 1.5707962513e+00f + 7.5497894159e-08f; // |y / x| >= 2^25, inf, NaN
+    const float zq = at - pi_lo;
+    float r = x < 0.0f ? pi - zq : at;             // (x = -0 is not "negative" here: atan2(y, -0) = +-pi/2)
+    if (!SAFE && y == 0.0f) r = pv_u2f((uint32_t)((int32_t)pv_f2u(x) >> 31) & pv_f2u(pi)); // atan2(+-0, x): +-0, +-pi
+    (void)pi_o_2;
+    return pv_u2f(pv_f2u(r) | (pv_f2u(y) & 0x80000000u));
+}
+#endif

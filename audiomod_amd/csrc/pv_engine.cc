@@ -361,6 +361,10 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
             return PV_ERR_NO_DEVICE;
         }
     }
+    if (!lds_starts_at_zero()) {
+        g_last_error = "internal: an analysis kernel was built with static LDS (its atan2f table address assumes none)";
+        return PV_ERR_HIP;
+    }
     S = nstreams;
     C = cfg.channels;
     rows = S * C;

@@ -40,6 +40,30 @@ __global__ void pv_atan2f_probe(const float *__restrict__ y, const float *__rest
     if (i < n) out[i] = pv_atan2f_fd_finite(y[i], x[i]);
 }
 
+// ... and the wave-per-frame kernels' polar conversion (table-driven atan2f, range-tested short division and square
+// root, IEEE operations otherwise: pv_kernels.hip analyze_wave_role), for pv_debug_polar
+__device__ const PvAtanBlob pv_atan_blob_probe = pv_atan_make_blob();
+__global__ void pv_polar_probe(const float *__restrict__ im, const float *__restrict__ re, float *__restrict__ ph,
+                               float *__restrict__ mag, int64_t n) {
+    __shared__ __attribute__((aligned(16))) uint32_t tab[PV_ATAN_BLOB_WORDS];
+    if (threadIdx.x < PV_ATAN_BLOB_WORDS) tab[threadIdx.x] = pv_atan_blob_probe.w[threadIdx.x];
+    __syncthreads();
+    typedef __attribute__((address_space(3))) const unsigned char lds_u8;
+    const unsigned char *atab = reinterpret_cast<const unsigned char *>((uintptr_t)(lds_u8 *)tab); // LDS address as a number
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float y = im[i], x = re[i];
+    const float a = x * x + y * y;
+    const float mx = fmaxf(fabsf(x), fabsf(y)), mn = fminf(fabsf(x), fabsf(y));
+    if (mx < 0x1p63f && mn >= 0x1p-48f) {
+        mag[i] = pv_sqrt_safe(a);
+        ph[i] = pv_atan2f_fd_tab<true>(y, x, atab);
+    } else {
+        mag[i] = sqrtf(a);
+        ph[i] = pv_atan2f_fd_tab<false>(y, x, atab);
+    }
+}
+
 constexpr int kSlots = 3; // groups in flight
 
 } // namespace
@@ -68,6 +92,24 @@ int pv_debug_atan2f(const float *y, const float *x, float *out, int64_t n, int d
     if (ok) {
         hipLaunchKernelGGL(pv_atan2f_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d, d + n, d + 2 * n, n);
         ok = hipMemcpy(out, d + 2 * n, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d);
+    return ok ? PV_OK : PV_ERR_HIP;
+}
+
+int pv_debug_polar(const float *im, const float *re, float *phase, float *mag, int64_t n, int device) {
+    if (n < 0 || (n > 0 && (!im || !re || !phase || !mag))) return PV_ERR_INVALID_ARG;
+    if (n == 0) return PV_OK;
+    float *d = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&d, (size_t)n * 4 * sizeof(float)) != hipSuccess)
+        return PV_ERR_HIP;
+    bool ok = hipMemcpy(d, im, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + n, re, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(pv_polar_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d, d + n, d + 2 * n,
+                           d + 3 * n, n);
+        ok = hipMemcpy(phase, d + 2 * n, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(mag, d + 3 * n, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess;
     }
     (void)hipFree(d);
     return ok ? PV_OK : PV_ERR_HIP;

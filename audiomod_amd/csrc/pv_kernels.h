@@ -275,6 +275,7 @@ struct StreamArgs {
 bool stream_kernel_supported(const StreamArgs &s);  // wave-FFT sizes only (nc 1024 / 2048)
 void launch_stream(const StreamArgs &s, hipStream_t st);
 
+bool lds_starts_at_zero(); // build invariant of the wave-per-frame analysis kernels (see pv_kernels.hip)
 void launch_analyze(const AnalyzeArgs &a, hipStream_t st);
 void launch_match(const MatchArgs &a, hipStream_t st);
 void launch_seq(const SeqArgs &a, hipStream_t st);

@@ -59,6 +59,14 @@ __device__ __forceinline__ double princarg(double a) {
     return (x - (y * n)) + PV_PI;
 }
 
+// atan2f's interval table (pv_atan2f.h) as the kernels read it into LDS
+__device__ const PvAtanBlob pv_atan_blob_dev = pv_atan_make_blob();
+__device__ __forceinline__ float pv_max3_abs(float a, float b, float c) {
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c));
+}
+__device__ __forceinline__ float pv_min3_abs(float a, float b, float c) {
+    return __builtin_fminf(__builtin_fminf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c));
+}
 __device__ __forceinline__ void wave_sync() {
     // LDS operations of one wave execute in issue order; this only stops the compiler from moving LDS
     // accesses across the hand-off between two passes
@@ -264,11 +272,19 @@ template <int WPB> __device__ __forceinline__ bool block_to_row_slice_w(int Tn, 
 }
 
 // (the body is a device function of (row, slice) so that the single-launch streaming kernel can call it too)
-template <int NC>
+// ATAB: the LDS address of atan2f's interval table as a compile-time number -- the kernels that call this have no
+// static LDS, so their dynamic LDS starts at address 0 (checked on the host: lds_starts_at_zero) and the table's
+// offsets fold into the LDS instructions' immediate fields (two vector adds fewer per bin)
+template <int NC, uint32_t ATAB>
 __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const int row, const int tl, cf *lds) {
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const unsigned char *atab = reinterpret_cast<const unsigned char *>((uintptr_t)ATAB);
     using W = WF<NC>;
     constexpr int N = 2 * NC, hs = NC, R = W::R;
     const int lane = threadIdx.x & 63;
+    // atan2f's interval table (pv_atan2f.h): 256 bytes of LDS behind the waves' regions, (re)written by every wave
+    // with the same words before its polar conversion reads them
+    const uint32_t atab_word = pv_atan_blob_dev.w[lane];
     const DevTables &tb = a.tb;
     const int64_t t = a.t0 + tl;
     const int slot = ring_slot(a.s0, tl, a.TR);
@@ -425,30 +441,57 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
     // for the peak search: a run's four floats land on the first half of the 32 bytes its cartesian values
     // occupied, and every later run lies beyond them.
     float *smag = reinterpret_cast<float *>(lds);
-    const cf xnyq = lds[NC];
+    *(lds_u32 *)(uintptr_t)(ATAB + 4u * (uint32_t)lane) = atab_word;
+    // DC and Nyquist have a zero imaginary part by construction (kiss_fftr.c:97-102): atan2f(+0, r) is +0 or pi by
+    // r's sign bit and the magnitude sqrtf(r r + 0 0); lanes 0 and 1 do both at once, and the loop below sees (1, 1)
+    // in the DC slot, so that its operand-range test is not tripped by that zero in every frame.
+    float edge_mag = 0.f, edge_ph = 0.f;
+    if (lane < 2) {
+        const cf e = lds[lane == 0 ? 0 : NC];
+        edge_mag = sqrtf(e.x * e.x + 0.f * 0.f);
+        edge_ph = pv_u2f((uint32_t)((int32_t)pv_f2u(e.x) >> 31) & pv_f2u(3.1415927410e+00f));
+    }
+    wave_sync();
+    if (lane == 0) lds[0] = cf{1.f, 1.f};
+    wave_sync();
 #pragma nounroll
     for (int q = 0; q < NC / 256; ++q) {
         const int i4 = 4 * (lane + 64 * q);
         const float4 c01 = *reinterpret_cast<const float4 *>(lds + i4);     // bins i4, i4 + 1
         const float4 c23 = *reinterpret_cast<const float4 *>(lds + i4 + 2); // bins i4 + 2, i4 + 3
         float4 m4, p4;
-        m4.x = sqrtf(c01.x * c01.x + c01.y * c01.y);
-        m4.y = sqrtf(c01.z * c01.z + c01.w * c01.w);
-        m4.z = sqrtf(c23.x * c23.x + c23.y * c23.y);
-        m4.w = sqrtf(c23.z * c23.z + c23.w * c23.w);
-        p4.x = pv_atan2f_fd_finite(c01.y, c01.x);
-        p4.y = pv_atan2f_fd_finite(c01.w, c01.z);
-        p4.z = pv_atan2f_fd_finite(c23.y, c23.x);
-        p4.w = pv_atan2f_fd_finite(c23.w, c23.z);
+        const float a0 = c01.x * c01.x + c01.y * c01.y, a1 = c01.z * c01.z + c01.w * c01.w;
+        const float a2 = c23.x * c23.x + c23.y * c23.y, a3 = c23.z * c23.z + c23.w * c23.w;
+        // The short division and square root of pv_atan2f.h need normal operands with magnitudes in [2^-48, 2^63):
+        // tested once per run of four bins and wave (true for spectra of audio unless a value is exactly zero --
+        // digital silence -- or vanishingly small; the IEEE operations of the other branch serve those).
+        const float mx = __builtin_fmaxf(__builtin_fmaxf(pv_max3_abs(c01.x, c01.y, c01.z), pv_max3_abs(c01.w, c23.x, c23.y)),
+                                         __builtin_fmaxf(__builtin_fabsf(c23.z), __builtin_fabsf(c23.w)));
+        const float mn = __builtin_fminf(__builtin_fminf(pv_min3_abs(c01.x, c01.y, c01.z), pv_min3_abs(c01.w, c23.x, c23.y)),
+                                         __builtin_fminf(__builtin_fabsf(c23.z), __builtin_fabsf(c23.w)));
+        const bool in_range = mx < 0x1p63f && mn >= 0x1p-48f;
+        if (__builtin_amdgcn_ballot_w64(!in_range) == 0) {
+            m4 = make_float4(pv_sqrt_safe(a0), pv_sqrt_safe(a1), pv_sqrt_safe(a2), pv_sqrt_safe(a3));
+            p4.x = pv_atan2f_fd_tab<true>(c01.y, c01.x, atab);
+            p4.y = pv_atan2f_fd_tab<true>(c01.w, c01.z, atab);
+            p4.z = pv_atan2f_fd_tab<true>(c23.y, c23.x, atab);
+            p4.w = pv_atan2f_fd_tab<true>(c23.w, c23.z, atab);
+        } else {
+            m4 = make_float4(sqrtf(a0), sqrtf(a1), sqrtf(a2), sqrtf(a3));
+            p4.x = pv_atan2f_fd_tab<false>(c01.y, c01.x, atab);
+            p4.y = pv_atan2f_fd_tab<false>(c01.w, c01.z, atab);
+            p4.z = pv_atan2f_fd_tab<false>(c23.y, c23.x, atab);
+            p4.w = pv_atan2f_fd_tab<false>(c23.w, c23.z, atab);
+        }
+        if (q == 0 && lane == 0) p4.x = edge_ph, m4.x = edge_mag;
         *reinterpret_cast<float4 *>(ph + i4) = p4;
         *reinterpret_cast<float4 *>(mag + i4) = m4;
         *reinterpret_cast<float4 *>(smag + i4) = m4;
     }
-    if (lane == 0) {
-        const float mn = sqrtf(xnyq.x * xnyq.x + xnyq.y * xnyq.y);
-        ph[NC] = pv_atan2f_fd_finite(xnyq.y, xnyq.x);
-        mag[NC] = mn;
-        smag[NC] = mn;
+    if (lane == 1) {
+        ph[NC] = edge_ph;
+        mag[NC] = edge_mag;
+        smag[NC] = edge_mag;
     }
     wave_sync();
     if (!a.find_peaks) return;
@@ -481,7 +524,7 @@ template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyz
     cf *lds = reinterpret_cast<cf *>(smem_raw) + (threadIdx.x >> 6) * WF<NC>::LDS_CF;
     int row, tl;
     if (!block_to_row_slice_w<WPB>(a.Tn, a.rows, row, tl)) return; // wave-uniform
-    analyze_wave_role<NC>(a, row, tl, lds);
+    analyze_wave_role<NC, WPB * WF<NC>::LDS_CF * sizeof(cf)>(a, row, tl, lds);
 }
 
 // Kernels may need more than the default 64 KiB of dynamic LDS.  hipFuncSetAttribute applies to the device that is
@@ -503,14 +546,14 @@ void launch_analyze(const AnalyzeArgs &a, hipStream_t st) {
             constexpr int WPB = 1; // one frame per workgroup: nothing couples the waves, and 8.6 KB of LDS each
             const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
             hipLaunchKernelGGL((pv_analyze_wave_kernel<1024, WPB>), dim3(grid), dim3(64 * WPB),
-                               WPB * WF<1024>::LDS_CF * sizeof(cf), st, a);
+                               WPB * WF<1024>::LDS_CF * sizeof(cf) + 4 * PV_ATAN_BLOB_WORDS, st, a);
         } else {
             constexpr int WPB = 1;
             const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
             static unsigned long long big = 0;
             allow_big_lds_dev(pv_analyze_wave_kernel<2048, WPB>, big);
             hipLaunchKernelGGL((pv_analyze_wave_kernel<2048, WPB>), dim3(grid), dim3(64 * WPB),
-                               WPB * WF<2048>::LDS_CF * sizeof(cf), st, a);
+                               WPB * WF<2048>::LDS_CF * sizeof(cf) + 4 * PV_ATAN_BLOB_WORDS, st, a);
         }
         return;
     }
@@ -2530,7 +2573,8 @@ template <int NC> __global__ __launch_bounds__(kStreamThreads) void pv_stream_ke
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = kStreamThreads / 64;
     const int Tn = s.aa.Tn, rows = s.aa.rows, work = rows * Tn;
     cf *wlds = reinterpret_cast<cf *>(smem_raw) + wave * WF<NC>::LDS_CF;
-    for (int i = wave; i < work; i += nw) analyze_wave_role<NC>(s.aa, i / Tn, i % Tn, wlds);
+    for (int i = wave; i < work; i += nw)
+        analyze_wave_role<NC, (kStreamThreads / 64) * WF<NC>::LDS_CF * sizeof(cf)>(s.aa, i / Tn, i % Tn, wlds);
     stage_handoff();
     if (s.coremode == 1) {
         // (slice-major order is not needed: a step only reads peak lists, all written by now)
@@ -2561,7 +2605,7 @@ template <int NC> __global__ __launch_bounds__(kStreamThreads) void pv_stream_ke
 
 static size_t stream_lds_bytes(const StreamArgs &s) {
     const size_t per_wave = (s.aa.tb.nc == 1024 ? WF<1024>::LDS_CF : WF<2048>::LDS_CF) * sizeof(cf);
-    size_t lds = (kStreamThreads / 64) * per_wave;
+    size_t lds = (kStreamThreads / 64) * per_wave + 4 * PV_ATAN_BLOB_WORDS; // + atan2f's interval table
     const size_t m = (kStreamThreads / 64) * match_wave_lds(s.ma.hs, s.ma.PKP);
     if (s.coremode == 1 && m > lds) lds = m;
     if (s.coremode == 1 && seq_lds_bytes(s.qa) > lds) lds = seq_lds_bytes(s.qa);
@@ -2571,6 +2615,21 @@ static size_t stream_lds_bytes(const StreamArgs &s) {
 
 bool stream_kernel_supported(const StreamArgs &s) {
     return (s.aa.tb.nc == 1024 || s.aa.tb.nc == 2048) && stream_lds_bytes(s) <= 160 * 1024 - 512;
+}
+
+// The wave-per-frame analysis code addresses atan2f's table by a compile-time LDS address, which is right only while
+// the kernels that contain it have no static LDS (their dynamic LDS then starts at 0).  The engine asks once per
+// device, at creation.
+bool lds_starts_at_zero() {
+    const void *ks[] = {reinterpret_cast<const void *>(pv_analyze_wave_kernel<1024, 1>),
+                        reinterpret_cast<const void *>(pv_analyze_wave_kernel<2048, 1>),
+                        reinterpret_cast<const void *>(pv_stream_kernel<1024>),
+                        reinterpret_cast<const void *>(pv_stream_kernel<2048>)};
+    for (const void *k : ks) {
+        hipFuncAttributes fa{};
+        if (hipFuncGetAttributes(&fa, k) != hipSuccess || fa.sharedSizeBytes != 0) return false;
+    }
+    return true;
 }
 
 void launch_stream(const StreamArgs &s, hipStream_t st) {

@@ -110,6 +110,7 @@ def lib():
     L.pv_hostio_out_frames.restype = C.c_int64
     L.pv_hostio_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.pv_debug_atan2f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+    L.pv_debug_polar.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
     L.pv_host_alloc.argtypes = [C.c_size_t]
     L.pv_host_alloc.restype = C.c_void_p
     L.pv_host_free.argtypes = [C.c_void_p]

@@ -184,6 +184,9 @@ const char *pv_kernel_name(int k);
 /* Diagnostics: the analysis kernels' atan2f (libm's algorithm restated, audiomod_amd/csrc/pv_atan2f.h, device build)
  * evaluated on host arrays of FINITE values -- tests compare it with the C library's atan2f bit for bit. */
 int pv_debug_atan2f(const float *y, const float *x, float *out, int64_t n, int device);
+/* ... and the polar conversion of the wave-per-frame analysis kernels (FFT.cc:2623-2630 mag = sqrtf(re^2 + im^2),
+ * phase = atan2f(im, re): table-driven atan2f, range-tested short division and square root) on FINITE values. */
+int pv_debug_polar(const float *im, const float *re, float *phase, float *mag, int64_t n, int device);
 
 #define PV_WIRE_F32 0
 #define PV_WIRE_I16 1

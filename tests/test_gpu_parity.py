@@ -696,3 +696,20 @@ def test_device_atan2f_is_libms_bit_for_bit():
     L.pvo_atan2f_array(y.ctypes.data, x.ctypes.data, want.ctypes.data, len(y))
     bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
     assert bad.size == 0, (bad.size, y[bad[:5]], x[bad[:5]], got[bad[:5]], want[bad[:5]])
+    # the wave-per-frame kernels' polar conversion (table-driven atan2f; short division and square root where the
+    # operands' range allows): phases against libm again, magnitudes against the correctly rounded sqrtf of the
+    # separately rounded re^2 + im^2 (FFT.cc:2623-2630 as the reference's x86 build evaluates it)
+    ew = rng.uniform(-14.4, 18.9, (2, n)).astype(np.float32)  # the whole range the fast path accepts, and beyond
+    sgw = rng.choice(np.array([-1.0, 1.0], np.float32), (2, n))
+    y = np.ascontiguousarray(np.concatenate([y, (10.0 ** ew[0]).astype(np.float32) * sgw[0]]), np.float32)
+    x = np.ascontiguousarray(np.concatenate([x, (10.0 ** ew[1]).astype(np.float32) * sgw[1]]), np.float32)
+    ph, mg, want = np.zeros_like(y), np.zeros_like(y), np.zeros_like(y)
+    E._check(E.lib().pv_debug_polar(y.ctypes.data, x.ctypes.data, ph.ctypes.data, mg.ctypes.data, len(y), 0),
+             "pv_debug_polar")
+    L.pvo_atan2f_array(y.ctypes.data, x.ctypes.data, want.ctypes.data, len(y))
+    bad = np.nonzero(ph.view(np.uint32) != want.view(np.uint32))[0]
+    assert bad.size == 0, (bad.size, y[bad[:5]], x[bad[:5]], ph[bad[:5]], want[bad[:5]])
+    with np.errstate(over="ignore", under="ignore"):
+        wm = np.sqrt((x * x).astype(np.float32) + (y * y).astype(np.float32), dtype=np.float32)
+    bad = np.nonzero(mg.view(np.uint32) != wm.view(np.uint32))[0]
+    assert bad.size == 0, (bad.size, y[bad[:5]], x[bad[:5]], mg[bad[:5]], wm[bad[:5]])
