@@ -26,6 +26,7 @@
 // (common/system/sys.h:84,91).
 #include "pv_kernels.h"
 #include "pv_atan2f.h"
+#include "pv_sincos.h"
 #include "pv_wavefft.h"
 
 #include <hip/hip_runtime.h>
@@ -1339,15 +1340,40 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
         return to_cartesian(mg, p);
     };
     if (plain) {
+        // The phases of the plain modes are wrapped (or a small multiple of a wrapped phase, core mode 2): the short
+        // sine / cosine of pv_sincos.h serves them; one wave-uniform test of the run's sixteen phases keeps the
+        // device library's for anything beyond its argument bound (and for NaN, which fails the comparison).
+        float pmax = __builtin_fabsf(pnyq);
 #pragma unroll
-        for (int q = 0; q < QB; ++q) {
-            if (q < QB / 2) mreg[q + QB / 2] = *reinterpret_cast<const float4 *>(mag + 4 * (lane + 64 * (q + QB / 2)));
-            xs[q][0] = to_cartesian(mreg[q].x, base[q].x);
-            xs[q][1] = to_cartesian(mreg[q].y, base[q].y);
-            xs[q][2] = to_cartesian(mreg[q].z, base[q].z);
-            xs[q][3] = to_cartesian(mreg[q].w, base[q].w);
+        for (int q = 0; q < QB; ++q)
+            pmax = __builtin_fmaxf(__builtin_fmaxf(pmax, pv_max3_abs(base[q].x, base[q].y, base[q].z)), __builtin_fabsf(base[q].w));
+        auto to_cartesian_small = [&](float mg, float p) -> cf {
+            mg *= a.inv_n;
+            float sn, cs;
+            pv_sincos_small(p, sn, cs);
+            return cf{mg * cs, mg * sn};
+        };
+        if (__builtin_amdgcn_ballot_w64(!(pmax <= PV_SINCOS_MAX_ARG)) == 0) {
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                if (q < QB / 2) mreg[q + QB / 2] = *reinterpret_cast<const float4 *>(mag + 4 * (lane + 64 * (q + QB / 2)));
+                xs[q][0] = to_cartesian_small(mreg[q].x, base[q].x);
+                xs[q][1] = to_cartesian_small(mreg[q].y, base[q].y);
+                xs[q][2] = to_cartesian_small(mreg[q].z, base[q].z);
+                xs[q][3] = to_cartesian_small(mreg[q].w, base[q].w);
+            }
+            if (lane == 0) xnyq = to_cartesian_small(mnyq, pnyq);
+        } else {
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                if (q < QB / 2) mreg[q + QB / 2] = *reinterpret_cast<const float4 *>(mag + 4 * (lane + 64 * (q + QB / 2)));
+                xs[q][0] = to_cartesian(mreg[q].x, base[q].x);
+                xs[q][1] = to_cartesian(mreg[q].y, base[q].y);
+                xs[q][2] = to_cartesian(mreg[q].z, base[q].z);
+                xs[q][3] = to_cartesian(mreg[q].w, base[q].w);
+            }
+            if (lane == 0) xnyq = to_cartesian(mnyq, pnyq);
         }
-        if (lane == 0) xnyq = to_cartesian(mnyq, pnyq);
     } else {
 #pragma unroll
         for (int q = 0; q < QB; ++q)
@@ -2237,11 +2263,33 @@ __device__ __forceinline__ void chain_slice_tail(const ChainArgs &c_in, const Ch
         q[j] = qq >= AQ ? qq - AQ : qq;
     }
     const bool tail_lane = lane == 0; // the quad behind the last full piece belongs to one lane
-    // zero goes back where a sample is inside [0, adv) relative to P_t
+    // What goes back to the ring: the sum, or zero where the sample is inside [0, adv) relative to P_t --
+    // as lane masks in scalar registers (no vector registers held across the wait), made before the turn for the
+    // two pieces that reach into the region for hops up to 512 - R samples; later pieces test in place.
+    constexpr int NM = NS < 2 ? NS : 2;
+    unsigned long long zero_at[NM][4];
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+        const int s0 = 4 * (lane + 64 * j) - R_;
+        zero_at[j][0] = __builtin_amdgcn_ballot_w64(s0 >= 0 && s0 < sl.adv);
+        zero_at[j][1] = __builtin_amdgcn_ballot_w64(s0 + 1 >= 0 && s0 + 1 < sl.adv);
+        zero_at[j][2] = __builtin_amdgcn_ballot_w64(s0 + 2 >= 0 && s0 + 2 < sl.adv);
+        zero_at[j][3] = __builtin_amdgcn_ballot_w64(s0 + 3 < sl.adv);
+    }
+    auto masked = [](float v, unsigned long long m) -> float { // lanes set in m get +0
+        float o;
+        asm("v_cndmask_b32 %0, %1, 0, %2" : "=v"(o) : "v"(v), "s"(m));
+        return o;
+    };
     auto write_back = [&](int j, const float4 v) -> float4 {
         const int s0 = 4 * (lane + 64 * j) - R_;
         float4 wb = v;
-        if (256 * j - R_ < sl.adv) { // wave-uniform: this piece reaches into the region
+        if (j < NM) {
+            wb.x = masked(v.x, zero_at[j < NM ? j : 0][0]);
+            wb.y = masked(v.y, zero_at[j < NM ? j : 0][1]);
+            wb.z = masked(v.z, zero_at[j < NM ? j : 0][2]);
+            wb.w = masked(v.w, zero_at[j < NM ? j : 0][3]);
+        } else if (256 * j - R_ < sl.adv) { // wave-uniform: this piece reaches into the region (hops above ~500)
             wb.x = (s0 >= 0 && s0 < sl.adv) ? 0.f : v.x;
             wb.y = (s0 + 1 >= 0 && s0 + 1 < sl.adv) ? 0.f : v.y;
             wb.z = (s0 + 2 >= 0 && s0 + 2 < sl.adv) ? 0.f : v.z;
@@ -2249,8 +2297,12 @@ __device__ __forceinline__ void chain_slice_tail(const ChainArgs &c_in, const Ch
         }
         return wb;
     };
+    // (Measured and left out: pinning the shifted frame, the ring addresses and the masks in registers in front of the
+    // wait, so that the compiler cannot sink their computation into the turn -- 0.320 -> 0.349 ms per launch with the
+    // frame pinned (spills), 0.320 with addresses and masks only.  Raising the wave's priority for the turn: 0.315.)
     // ---- the turn
     if (!(c.diag & 4)) chain_wait_turn(l.turn, tl);
+    __builtin_amdgcn_s_setprio(3); // the turn's instructions ahead of the three other waves of this SIMD
     float4 V[NS];
     if (!skip) {
 #pragma unroll
@@ -2261,11 +2313,13 @@ __device__ __forceinline__ void chain_slice_tail(const ChainArgs &c_in, const Ch
             if (j < NP || tail_lane) acc4[q[j]] = write_back(j, V[j]);
         }
     } else {
-        // a frame this channel does not add (CONSTANT-mode overrun): adv is 0 then, nothing is finalised either
+        // a frame this channel does not add (CONSTANT-mode overrun): adv is 0 then, nothing is finalised either and
+        // V is never looked at (left undefined rather than zero-filled: 36 moves the common path would execute too)
 #pragma unroll
-        for (int j = 0; j < NS; ++j) V[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < NS; ++j) asm volatile("" : "=v"(V[j].x), "=v"(V[j].y), "=v"(V[j].z), "=v"(V[j].w));
     }
     chain_pass_turn(l.turn, tl, lane);
+    __builtin_amdgcn_s_setprio(0);
     // ---- after the turn: normalise the finalised samples and append them to the stream (or emit them)
     float *__restrict__ out = c.out + (int64_t)row * c.out_stride_row + sl.k_off;
     float *__restrict__ stream = c.stream + (int64_t)row * ((int64_t)c.smask + 1);
