@@ -499,14 +499,32 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
     // ordered list first into LDS (behind the magnitudes), then out in whole 32-bit words: three coalesced
     // stores per lane instead of one sparsely populated 16-bit store per group of 64 bins
     uint16_t *slist = reinterpret_cast<uint16_t *>(smag + NC + 4); // [PKP], 16-byte aligned
+    // A lane tests four consecutive bins (one 16-byte read plus the two bins either side) against the larger of their
+    // four neighbours -- is_peak()'s four comparisons as one.  Two peaks are at least three bins apart, so a run of
+    // four holds none, one, or its first and last bin: the ordered list position is a prefix count over two lane masks.
+    // Bins 0, 1 and hs - 2, hs - 1 are never peaks (:587-596): their outer neighbours read as +infinity.
     int running = 0;
-#pragma unroll 8
-    for (int g = 0; g < hs / 64; ++g) {
-        const int b = lane + 64 * g;
-        const bool isp = is_peak(smag, b, hs);
-        const unsigned long long bm = __ballot(isp);
-        if (isp) slist[running + __popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)b;
-        running += __popcll(bm);
+    const float inf = __builtin_inff();
+#pragma unroll
+    for (int q = 0; q < NC / 256; ++q) {
+        const int i4 = 4 * (lane + 64 * q);
+        const float4 m = *reinterpret_cast<const float4 *>(smag + i4);
+        float2 lo = *reinterpret_cast<const float2 *>(smag + (q == 0 && lane == 0 ? 0 : i4 - 2));
+        float2 hi = *reinterpret_cast<const float2 *>(smag + i4 + 4);
+        if (q == 0 && lane == 0) lo = make_float2(inf, inf);
+        if (q == NC / 256 - 1 && lane == 63) hi = make_float2(inf, inf);
+        const float in01 = __builtin_fmaxf(m.x, m.y), in12 = __builtin_fmaxf(m.y, m.z), in23 = __builtin_fmaxf(m.z, m.w);
+        const bool f0 = m.x > __builtin_fmaxf(__builtin_fmaxf(lo.x, lo.y), in12);
+        const bool f1 = m.y > __builtin_fmaxf(__builtin_fmaxf(lo.y, m.x), in23);
+        const bool f2 = m.z > __builtin_fmaxf(in01, __builtin_fmaxf(m.w, hi.x));
+        const bool f3 = m.w > __builtin_fmaxf(in12, __builtin_fmaxf(hi.x, hi.y));
+        const bool any = f0 || f1 || f2 || f3, two = f0 && f3;
+        const unsigned long long ma = __ballot(any), mb = __ballot(two);
+        const int pos = running + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0u)) +
+                        (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
+        if (any) slist[pos] = (uint16_t)(i4 + (f0 ? 0 : f1 ? 1 : f2 ? 2 : 3));
+        if (two) slist[pos + 1] = (uint16_t)(i4 + 3);
+        running += __popcll(ma) + __popcll(mb);
     }
     if (lane == 0) {
         a.npk[plane] = running;
