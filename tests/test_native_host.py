@@ -65,3 +65,13 @@ def test_atan2f_restatement_is_bit_identical_to_libm(tmp_path):
     dev = open(os.path.join(ROOT, "audiomod_amd/csrc/pv_kernels.hip")).read()
     code = "\n".join(ln.split("//")[0] for ln in dev.splitlines())  # comments may mention libm's atan2f
     assert "pv_atan2f_fd_finite(" in code and " atan2f(" not in code and "(atan2f(" not in code
+
+
+def test_short_sincos_against_double(tmp_path):
+    """The synthesis kernels' sine / cosine for wrapped phases (audiomod_amd/csrc/pv_sincos.h: two-term reduction, own
+    polynomials, bit-operation quadrant step) against double-precision sin / cos: 40 M samples of [-pi, pi] and of the
+    whole accepted range, every float near each multiple of pi/4, special values; bar 2 ulp or 1.2e-7 absolute."""
+    r = _build_and_run(tmp_path, ["tests/native/host_sincos.cc"], "host_sincos")
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
+    dev = open(os.path.join(ROOT, "audiomod_amd/csrc/pv_kernels.hip")).read()
+    assert "pv_sincos_small(" in dev and "PV_SINCOS_MAX_ARG" in dev

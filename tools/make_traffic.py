@@ -49,7 +49,8 @@ def main():
         res[k] = int((2.0 * f_kib + w_kib) * 1024)
         detail[k] = {"FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib, "launches": len(c["FETCH_SIZE"])}
     json.dump({"note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, median launch; "
-                       "bench workload geometry (128 stereo streams, 256-slice chunks = 65536 slices per launch)",
+                       "bench workload geometry (128 stereo streams; since round 2's last change 512-slice chunks = 131072 slices "
+                       "per launch, 65536 before -- compare with the bench line's roofline.slices_per_launch)",
                "bytes_per_launch": res, "counters": detail}, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
