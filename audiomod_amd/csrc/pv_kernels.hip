@@ -21,8 +21,9 @@
 // Arithmetic contract: this file is compiled with -ffp-contract=off.  Every float expression
 // keeps the reference's operand order and rounding points so the FFT, magnitudes, peak picking,
 // OLA and resampler MACs are bit-identical to the x86 reference.  The analysis phases are too: atan2f is libm's own
-// algorithm (pv_atan2f.h), because the phase propagation is discontinuous in them.  Only sinf / cosf come from the
-// device libm (a few ulp; the output is continuous in them).  princarg stays in double with a true IEEE divide, as the reference
+// algorithm (pv_atan2f.h), because the phase propagation is discontinuous in them.  Only the synthesis' sine / cosine
+// are approximations of the reference's (pv_sincos.h for wrapped phases, the device libm elsewhere: 1-2 ulp; the output is
+// continuous in them).  princarg stays in double with a true IEEE divide, as the reference
 // (common/system/sys.h:84,91).
 #include "pv_kernels.h"
 #include "pv_atan2f.h"

@@ -21,8 +21,8 @@ def _rms(a, b):
 
 @pytest.mark.gpu
 def test_cfg5_per_gpu_share_at_full_size():
-    """128 stereo streams x 60 s through the batch engine exactly as bench.py drives it (rows = 256, 56 chunks of
-    64 K slices, pipelined): four streams spread over the grid (first, last, two mid-grid rows) against the oracle,
+    """128 stereo streams x 60 s through the batch engine exactly as bench.py drives it (rows = 256, 28 chunks of
+    128 K slices -- 56 of 64 K until the last change of round 2 -- pipelined): four streams spread over the grid (first, last, two mid-grid rows) against the oracle,
     duplicate-input streams bit for bit, and two runs of the same batch bit for bit."""
     import torch
 
@@ -35,7 +35,7 @@ def test_cfg5_per_gpu_share_at_full_size():
     dups = [(S - 1, 0), (S // 2, 1)]
     d_in = signals.synthetic_batch(torch, S, F, torch.device("cuda", 0), duplicates=dups)
     b = E.Batch(S, F, channels=2, block=480, flush=True, **kw)
-    assert b.pipelined and b.launches >= 50  # the geometry of the bench line, not a small stand-in
+    assert b.pipelined and b.launches >= 25  # the geometry of the bench line, not a small stand-in
     assert b.slices * 2 * S // b.launches >= 60000
     out = b.run(d_in)
     torch.cuda.synchronize()
