@@ -2297,7 +2297,7 @@ __device__ __forceinline__ void chain_slice_tail(const ChainArgs &c_in, const Ch
     }
     auto masked = [](float v, unsigned long long m) -> float { // lanes set in m get +0
         float o;
-        asm("v_cndmask_b32 %0, %1, 0, %2" : "=v"(o) : "v"(v), "s"(m));
+        asm("v_cndmask_b32_e64 %0, %1, 0, %2 ; pvmask" : "=v"(o) : "v"(v), "s"(m));
         return o;
     };
     auto write_back = [&](int j, const float4 v) -> float4 {
@@ -2316,9 +2316,17 @@ __device__ __forceinline__ void chain_slice_tail(const ChainArgs &c_in, const Ch
         }
         return wb;
     };
-    // (Measured and left out: pinning the shifted frame, the ring addresses and the masks in registers in front of the
-    // wait, so that the compiler cannot sink their computation into the turn -- 0.320 -> 0.349 ms per launch with the
-    // frame pinned (spills), 0.320 with addresses and masks only.  Raising the wave's priority for the turn: 0.315.)
+    // The masks are pinned in their scalar registers HERE, in front of the wait.  Not for speed (measured: pinning the
+    // shifted frame as well, so that the compiler cannot sink its selects into the turn, costs 0.320 -> 0.349 ms per
+    // launch in spills; addresses and masks only: 0.320; raised priority alone: 0.315) but for correctness: on gfx950 a
+    // VALU instruction that reads an SGPR written by a VALU instruction (the v_cmp behind a ballot) needs two wait states
+    // in between, the compiler's hazard recogniser inserts them for its own instructions only, and masked() is inline
+    // assembly -- left free, the compiler may put the compare right in front of it (seen as a rare wrong write-back:
+    // test_fused_overlap_add_is_bit_identical_to_the_tile_path failed once in four full runs).  With the compares
+    // forced to this side of the wait loop, the loop's own instructions are the distance.
+#pragma unroll
+    for (int j = 0; j < NM; ++j)
+        asm volatile("" : "+s"(zero_at[j][0]), "+s"(zero_at[j][1]), "+s"(zero_at[j][2]), "+s"(zero_at[j][3]));
     // ---- the turn
     if (!(c.diag & 4)) chain_wait_turn(l.turn, tl);
     __builtin_amdgcn_s_setprio(3); // the turn's instructions ahead of the three other waves of this SIMD

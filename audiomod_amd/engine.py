@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaudiomod_pv.so")
+# (AUDIOMOD_PV_LIB: a diagnostic build of the library -- tools/build_variant.sh -- instead of the product's)
+LIB_PATH = os.environ.get("AUDIOMOD_PV_LIB") or os.path.join(_HERE, "lib", "libaudiomod_pv.so")
 
 MODES = {"constant": -1, "normal_pitchshift": 0, "gender_change": 1, "formant_pitchshift": 2,
          "vocoder": 3, "vocoder_chord": 4, "time_stretch": 5, "robotic": 6, "whisper": 7,

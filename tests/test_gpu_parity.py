@@ -577,6 +577,9 @@ np.savez(sys.argv[1], *outs)
                                env=dict(os.environ, **env), timeout=900)
             assert r.returncode == 0, r.stdout + r.stderr
             files.append(np.load(f))
+            if os.environ.get("AUDIOMOD_PV_KEEP_NPZ"):  # debugging aid: keep what was compared
+                import shutil
+                shutil.copy(f, os.path.join(os.environ["AUDIOMOD_PV_KEEP_NPZ"], tag + ".npz"))
         a, b = files
         assert len(a.files) == len(b.files) == 22
         for k in a.files:
