@@ -1823,8 +1823,100 @@ template <int NC> __global__ __launch_bounds__(64) void pv_cepstral_wave_kernel(
     cepstral_wave_role<NC>(a, row, tl, reinterpret_cast<cf *>(smem_raw));
 }
 
+// Any FFT size (round 2): one workgroup per (row, slice), both transforms through the generic LDS butterfly stages --
+// the same steps as the wave version above, the same arithmetic as the reference's formantShiftSlice
+// (phasevocoderprocess.cc:925-999), which is size-agnostic.
+__global__ __launch_bounds__(kFftThreads) void pv_cepstral_kernel(const CepstralArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const DevTables &tb = a.tb;
+    const int hs = tb.hs, nc = tb.nc, nt = blockDim.x;
+    constexpr int kCut = 60;
+    float2 *buf = reinterpret_cast<float2 *>(smem_raw); // [nc]      butterfly array
+    float2 *X = buf + nc;                               // [nc + 1]  log-magnitude spectrum
+    float *senv = reinterpret_cast<float *>(X + nc + 1); // [hs + 1] envelope
+    float *scep = senv + hs + 4;                        // [64]      the surviving quefrencies
+    int row, tl;
+    if (!block_to_row_slice(a.Tn, a.rows, row, tl)) return;
+    const int64_t plane = (int64_t)row * a.TR + ring_slot(a.s0, tl, a.TR);
+    float *__restrict__ mag = a.mag + plane * tb.HP;
+    for (int k = threadIdx.x; k <= hs; k += nt) X[k] = make_float2(logf(mag[k] + 0.000001f), 0.f);
+    __syncthreads();
+    // kiss_fftri pre-pass (kiss_fftr.c:134-157) scattered into butterfly order, inverse stages: buf = cep pairs
+    for (int k = threadIdx.x; k <= nc / 2; k += nt) {
+        if (k == 0) {
+            buf[tb.iperm[0]] = make_float2(X[0].x + X[nc].x, X[0].x - X[nc].x);
+        } else {
+            const float2 fk = X[k];
+            const float2 q = X[nc - k];
+            const float2 fnkc = make_float2(q.x, -q.y);
+            const float2 fek = cadd(fk, fnkc);
+            const float2 tq = csub(fk, fnkc);
+            const float2 fok = cmul(tq, tb.st_inv[k]);
+            const float2 u = cadd(fek, fok);
+            float2 v = csub(fek, fok);
+            v.y = v.y * -1.f;
+            if (k != nc - k) buf[tb.iperm[k]] = u;
+            buf[tb.iperm[nc - k]] = v;
+        }
+    }
+    __syncthreads();
+    fft_stages<true>(buf, tb, tb.tw_inv);
+    // lifter: the first 60 quefrencies survive, the two ends halved, all times 1 / N (:952-960)
+    if (threadIdx.x < 64) {
+        const float *cep = reinterpret_cast<const float *>(buf);
+        float c = threadIdx.x < kCut ? cep[threadIdx.x] : 0.f;
+        if (threadIdx.x == 0 || threadIdx.x == kCut - 1) c = c / 2;
+        scep[threadIdx.x] = threadIdx.x < kCut ? c * a.inv_n : 0.f;
+    }
+    __syncthreads();
+    // forward real transform of the zero-extended sequence (kiss_fftr.c:67-121): pairs in butterfly order
+    for (int j = threadIdx.x; j < nc; j += nt) {
+        const int src = tb.perm[j];
+        buf[j] = src < 32 ? make_float2(scep[2 * src], scep[2 * src + 1]) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    fft_stages<false>(buf, tb, tb.tw_fwd);
+    for (int k = threadIdx.x; k <= nc / 2; k += nt) {
+        if (k == 0) {
+            const float2 tdc = buf[0];
+            senv[0] = expf(tdc.x + tdc.y);
+            senv[nc] = expf(tdc.x - tdc.y);
+        } else {
+            const float2 fpk = buf[k];
+            const float2 q = buf[nc - k];
+            const float2 fpnk = make_float2(q.x, -q.y);
+            const float2 f1k = cadd(fpk, fpnk);
+            const float2 f2k = csub(fpk, fpnk);
+            const float2 tq = cmul(f2k, tb.st_fwd[k]);
+            if (k != nc - k) senv[k] = expf((f1k.x + tq.x) * 0.5f);
+            senv[nc - k] = expf((f1k.x - tq.x) * 0.5f);
+        }
+    }
+    __syncthreads();
+    // whiten by the envelope, re-colour by the envelope read at lrint(k * env_comp) (:962-998)
+    for (int k = threadIdx.x; k <= hs; k += nt) {
+        float sh;
+        if (a.env_comp > 1.0f) {
+            const int src = __float2int_rn((float)k * a.env_comp);
+            sh = src > hs ? 0.f : senv[src];
+        } else if (k == hs) {
+            sh = senv[hs]; // the downward loop of the reference never touches the Nyquist bin
+        } else {
+            sh = senv[__float2int_rn((float)k * a.env_comp)];
+        }
+        mag[k] = (mag[k] / senv[k]) * sh;
+    }
+}
+
 void launch_cepstral(const CepstralArgs &a, hipStream_t st) {
     const int grid = 8 * ((a.rows + 7) / 8) * a.Tn;
+    if (a.tb.nc != 1024 && a.tb.nc != 2048) {
+        const size_t lds = (size_t)(2 * a.tb.nc + 1) * sizeof(float2) + sizeof(float) * (a.tb.hs + 4 + 64);
+        static unsigned long long big = 0;
+        allow_big_lds_dev(pv_cepstral_kernel, big);
+        hipLaunchKernelGGL(pv_cepstral_kernel, dim3(grid), dim3(kFftThreads), lds, st, a);
+        return;
+    }
     if (a.tb.nc == 1024) {
         hipLaunchKernelGGL((pv_cepstral_wave_kernel<1024>), dim3(grid), dim3(64), WF<1024>::LDS_CF * sizeof(cf), st, a);
     } else {

@@ -286,7 +286,7 @@ int derive(const pv_config &cfg, Derived &d) {
     d.fixed_gain = d.pitch_scale > 1 ? d.pitch_scale : 1 / d.pitch_scale;
     // extension mode: formantShiftSlice(channel, m_pitchScale) where formantPreserveSlice has it commented out
     if (cfg.mode == PV_MODE_FORMANT_CEPSTRAL) {
-        if (d.N != 2048 && d.N != 4096) return PV_ERR_UNSUPPORTED;
+        if (d.N < 128) return PV_ERR_UNSUPPORTED; // the lifter keeps 60 quefrencies: needs at least 64 bins
         if (d.pitch_scale != 1.0) {
             d.cepstral = true;
             d.env_comp = d.pitch_scale;

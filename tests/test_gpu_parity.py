@@ -403,9 +403,13 @@ def test_full_size_other_baseline_configs(name, kw):
 
 
 @pytest.mark.parametrize("kw", [dict(semitones=4.0), dict(semitones=-7.0), dict(semitones=7.0, fftsize=4096),
-                                dict(semitones=4.0, coremode=0), dict(semitones=0.0)])
+                                dict(semitones=4.0, coremode=0), dict(semitones=0.0),
+                                dict(semitones=5.0, fftsize=1024), dict(semitones=-4.0, fftsize=512),
+                                dict(semitones=3.0, fftsize=8192, coremode=2), dict(semitones=-9.0, fftsize=256)])
 def test_formant_cepstral_mode(kw):
-    """extension mode: the reference's (unreachable) cepstral formant shift, oracle pinned on the real function"""
+    """extension mode: the reference's (unreachable) cepstral formant shift, oracle pinned on the real function; every
+    FFT size (2048 / 4096: one wave per slice; the others, since round 2: one workgroup per slice through the generic
+    LDS transforms -- formantShiftSlice itself is size-agnostic)"""
     x = signals.voice(30000, 2, seed=91)
     want, wc, _ = O.run_offline(x, mode="formant_cepstral", **kw)
     got, gc = E.run_offline(x, mode="formant_cepstral", **kw)
@@ -413,7 +417,7 @@ def test_formant_cepstral_mode(kw):
     assert rms(got, want) <= RMS_TOL
     if kw.get("semitones"):
         plain, _, _ = O.run_offline(x, mode="normal_pitchshift", **kw)
-        assert rms(want, plain) > 50 * RMS_TOL  # the mode really does something
+        assert rms(want, plain) > 20 * RMS_TOL  # the mode really does something
     # and through the batch API
     import torch
     b = E.Batch(2, x.shape[1], channels=2, mode="formant_cepstral", **kw)
@@ -424,9 +428,10 @@ def test_formant_cepstral_mode(kw):
     b.close()
 
 
-def test_formant_cepstral_needs_a_wave_fft_size():
+def test_formant_cepstral_needs_room_for_its_lifter():
+    """the lifter keeps 60 quefrencies: frames below 128 points are refused (every larger size is served)"""
     with pytest.raises(E.PvError):
-        E.PhaseVocoder(48000, 2, 1.0, 4.0, E.FORMANT_CEPSTRAL, 1, 1024)
+        E.PhaseVocoder(48000, 2, 1.0, 4.0, E.FORMANT_CEPSTRAL, 1, 64)
 
 
 # Configurations the randomised sweep (tests/sweeps/fuzz_parity.py) turned up as refused or wrong at some point.

@@ -1,3 +1,4 @@
+import os
 """The oracle (oracle/pv_oracle.c) against the golden vectors captured from the compiled
 reference (tools/make_golden.py).  Bit-exact: same x86-64 arithmetic model, same libm."""
 import numpy as np
@@ -79,6 +80,19 @@ def test_resampler(kat, tag):
 @pytest.mark.parametrize("tag", ["+4", "-7", "1"])
 def test_cepstral_formant_shift(kat, N, tag):
     """formantShiftSlice (dead code upstream, called directly by oracle/_ref/ref_formant): bit-exact"""
+    L = O.lib()
+    mags = kat[f"formant{N}_in"].copy()
+    env = float(kat[f"formant{N}_{tag}_env"][0])
+    for r in range(mags.shape[0]):
+        L.pvo_formant_shift(N, mags[r].ctypes.data, env)
+    assert bits_equal(mags, kat[f"formant{N}_{tag}_out"])
+
+
+@pytest.mark.parametrize("N", [256, 512, 1024, 8192])
+@pytest.mark.parametrize("tag", ["+5", "-9", "1"])
+def test_cepstral_formant_shift_other_sizes(N, tag):
+    """the same at the FFT sizes the engine serves through its generic kernels (tools/make_golden_formant_sizes.py)"""
+    kat = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_formant_sizes.npz"))
     L = O.lib()
     mags = kat[f"formant{N}_in"].copy()
     env = float(kat[f"formant{N}_{tag}_env"][0])
