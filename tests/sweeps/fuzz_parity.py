@@ -33,8 +33,8 @@ def draw(rng):
                       "robotic", "constant", "vocoder", "vocoder_chord", "formant_cepstral", "whisper"])
     kw = dict(mode=str(mode))
     kw["fftsize"] = int(rng.choice([256, 512, 1024, 2048, 2048, 2048, 4096, 4096, 8192]))
-    if mode == "formant_cepstral":
-        kw["fftsize"] = int(rng.choice([2048, 4096]))
+    if mode == "formant_cepstral":  # every size since round 2 (the lifter needs 128 points or more)
+        kw["fftsize"] = int(rng.choice([256, 512, 1024, 2048, 4096, 8192]))
     kw["coremode"] = int(rng.choice([0, 1, 1, 2]))
     kw["sample_rate"] = int(rng.choice([8000, 16000, 22050, 44100, 48000, 48000, 96000]))
     if mode == "time_stretch":
