@@ -180,17 +180,21 @@ constexpr PvAtanBlob pv_atan_make_blob() {
     return b;
 }
 
-// sqrtf(a) for a normal a in [2^-96, 2^127): the hardware square root (1 ulp) stepped to the correctly rounded
-// neighbour by the signs of the two exact residuals a - s (s -+ 1 ulp) -- the compiler's own expansion of sqrtf
-// without the input scaling and the zero / infinity pass-through that this range does not need.  Host: sqrtf.
+// sqrtf(a) for a normal a in [2^-96, 2^127), correctly rounded, in five instructions: y = rsq(a) (1 ulp), s0 = a y,
+// the EXACT residual d = a - s0 s0 (fma), and s0 + d (y / 2) in one more fma.  With s0 = r (1 + e0) and
+// y / 2 = (1 + eh) / 2r the sum before the final rounding is r (1 - e0^2 / 2 - e0 eh), i.e. within ~2^-20 ulp of
+// sqrt(a) -- close enough that only a value of sqrt(a) within that distance of a rounding boundary could round the
+// other way, and there is no such float: the device test sweeps EVERY float of the range against the compiler's
+// correctly rounded sqrtf (pv_debug_sqrt_sweep, tests/test_gpu_parity.py: 1.87e9 values, 0 mismatches).  The
+// compiler's own expansion (v_sqrt, two neighbours, two residuals, two compares, two selects) is nine instructions,
+// the selects among the expensive ones (tools/pk_probe.hip).  Host: sqrtf.
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ float pv_sqrt_safe(const float a) {
-    const float s = __builtin_amdgcn_sqrtf(a);
-    const float sm = pv_u2f(pv_f2u(s) - 1u), sp = pv_u2f(pv_f2u(s) + 1u);
-    const float em = __builtin_fmaf(-sm, s, a), ep = __builtin_fmaf(-sp, s, a);
-    float r = em <= 0.0f ? sm : s;
-    r = ep > 0.0f ? sp : r;
-    return r;
+    const float y = __builtin_amdgcn_rsqf(a);
+    const float s0 = a * y;
+    const float h = 0.5f * y;
+    const float d = __builtin_fmaf(-s0, s0, a);
+    return __builtin_fmaf(d, h, s0);
 }
 #else
 PV_AT_HD float pv_sqrt_safe(const float a) { return __builtin_sqrtf(a); }

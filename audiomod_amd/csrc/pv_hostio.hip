@@ -64,6 +64,25 @@ __global__ void pv_polar_probe(const float *__restrict__ im, const float *__rest
     }
 }
 
+// every float with bit pattern in [first, first + count): pv_sqrt_safe against the compiler's correctly rounded sqrtf
+__global__ void pv_sqrt_sweep_kernel(uint32_t first, uint64_t count, unsigned long long *res) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    uint32_t first_bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint32_t u = first + (uint32_t)i;
+        const float a = pv_u2f(u);
+        if (pv_f2u(pv_sqrt_safe(a)) != pv_f2u(sqrtf(a))) {
+            if (!bad) first_bad = u;
+            ++bad;
+        }
+    }
+    if (bad) {
+        atomicAdd(&res[0], bad);
+        atomicMin(&res[1], (unsigned long long)first_bad);
+    }
+}
+
 constexpr int kSlots = 3; // groups in flight
 
 } // namespace
@@ -112,6 +131,21 @@ int pv_debug_polar(const float *im, const float *re, float *phase, float *mag, i
              hipMemcpy(mag, d + 3 * n, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess;
     }
     (void)hipFree(d);
+    return ok ? PV_OK : PV_ERR_HIP;
+}
+
+int pv_debug_sqrt_sweep(uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint32_t *first_bad, int device) {
+    if (!mismatches || !first_bad) return PV_ERR_INVALID_ARG;
+    unsigned long long *d = nullptr, h[2] = {0ull, ~0ull};
+    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&d, sizeof(h)) != hipSuccess) return PV_ERR_HIP;
+    bool ok = hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && count) {
+        hipLaunchKernelGGL(pv_sqrt_sweep_kernel, dim3(4096), dim3(256), 0, nullptr, first_bits, (uint64_t)count, d);
+        ok = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d);
+    *mismatches = h[0];
+    *first_bad = (uint32_t)h[1];
     return ok ? PV_OK : PV_ERR_HIP;
 }
 

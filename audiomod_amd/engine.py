@@ -112,6 +112,7 @@ def lib():
     L.pv_hostio_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.pv_debug_atan2f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
     L.pv_debug_polar.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+    L.pv_debug_sqrt_sweep.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_int]
     L.pv_host_alloc.argtypes = [C.c_size_t]
     L.pv_host_alloc.restype = C.c_void_p
     L.pv_host_free.argtypes = [C.c_void_p]

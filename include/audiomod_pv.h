@@ -187,6 +187,9 @@ int pv_debug_atan2f(const float *y, const float *x, float *out, int64_t n, int d
 /* ... and the polar conversion of the wave-per-frame analysis kernels (FFT.cc:2623-2630 mag = sqrtf(re^2 + im^2),
  * phase = atan2f(im, re): table-driven atan2f, range-tested short division and square root) on FINITE values. */
 int pv_debug_polar(const float *im, const float *re, float *phase, float *mag, int64_t n, int device);
+/* ... and its short square root against the correctly rounded one on EVERY float whose bit pattern lies in
+ * [first_bits, first_bits + count): the number of mismatches and the first offending pattern. */
+int pv_debug_sqrt_sweep(uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint32_t *first_bad, int device);
 
 #define PV_WIRE_F32 0
 #define PV_WIRE_I16 1

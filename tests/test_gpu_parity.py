@@ -594,6 +594,17 @@ np.savez(sys.argv[1], *outs)
             assert bits_equal(a[f"arr_{i}"][1], a[f"arr_{i + 1}"]), i
 
 
+def test_short_square_root_is_correctly_rounded_on_every_float_of_its_range():
+    """pv_sqrt_safe (pv_atan2f.h: rsq, one multiply, an exact residual, one fma) against the compiler's correctly rounded
+    sqrtf on EVERY float in [2^-96, 2^127) -- the range the analysis kernels' fast path guarantees for re^2 + im^2."""
+    import ctypes as C
+    lo = int(np.float32(2.0 ** -96).view(np.uint32))
+    hi = int(np.float32(2.0 ** 127).view(np.uint32))
+    bad, first = C.c_uint64(0), C.c_uint32(0)
+    E._check(E.lib().pv_debug_sqrt_sweep(lo, hi - lo, C.byref(bad), C.byref(first), 0), "pv_debug_sqrt_sweep")
+    assert bad.value == 0, (bad.value, hex(first.value))
+
+
 OVERRUN_GPU = [
     (dict(semitones=-3.0), 2, [100000, 480, 480, 50000, 480, 480]),
     (dict(semitones=5.0, fftsize=256), 2, [6000, 6000, 64, 6000]),
