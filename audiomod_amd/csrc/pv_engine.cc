@@ -335,7 +335,8 @@ struct Core {
         // when it runs beside it (measured: 13.42 vs 13.47 Gsamples/s), coremode 2 has no phase kernel
         // ... and frames up to 2048 points: at 4096 the synthesis waves hold 240 VGPRs, two to a SIMD, and lose
         // more to the chain's waves beside them than the overlap returns (measured: 9.65 vs 9.77 Gsamples/s)
-        return phase_stage && cfg.coremode == 1 && cfg.fftsize <= 2048;
+        // (AUDIOMOD_PV_PIPELINE=2 forces it for the larger frames too: for measurements)
+        return phase_stage && cfg.coremode == 1 && (cfg.fftsize <= 2048 || (e && atoi(e) == 2));
     }
     bool can_overlap_chain() const { return pipelined_planes; }
 };
