@@ -72,6 +72,12 @@ template <typename T> struct DevBuf {
         release();
         n = count;
         HIPC(hipMalloc((void **)&p, (count ? count : 1) * sizeof(T)));
+        // Every device buffer starts as zeros (a creation-time cost only).  The kernels read nothing they have not
+        // written except slots whose values are provably unused (records and rotations of lanes beyond a step's peak
+        // count), but "provably unused" deserves a belt: with this, what such a slot holds cannot depend on what the
+        // memory held before -- round 2 saw one bit-identity test fail twice, with identical garbage in one output
+        // sample, on what was probably one box of the pool, and never again.
+        HIPC(hipMemset(p, 0, (count ? count : 1) * sizeof(T)));
         return PV_OK;
     }
     int upload(const std::vector<T> &v) {
