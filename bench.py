@@ -417,6 +417,21 @@ def main():
         achieved = round(dom_bytes * slices_per_launch / (main[dom]["avg_ms"] * 1e-3) / 1e9, 1) \
             if dom_stage != "phase" or not overlapped else per_stage[dom_stage]["GBps"]
         traffic = traffic_db.get(dom) if (G == 1 and args.streams == 128 and args.config == "cfg2") else None
+        # Beside the contract's HBM figure: how close the same kernel runs to the chip's vector-instruction issue rate,
+        # which is what bounds this path.  Instruction counts per slice and the mean issue cost
+        # of the kernel's instruction mix are a profile's (profiles/valu.json: PMC pass + tools/pk_probe.hip's price
+        # list), the duration is this run's.
+        valu = None
+        vpath = os.path.join(ROOT, "profiles", "valu.json")
+        if os.path.exists(vpath) and G == 1 and args.streams == 128 and args.config == "cfg2" and args.coremode == 1:
+            vdb = json.load(open(vpath))
+            vk = vdb.get("kernels", {}).get(dom)
+            if vk:
+                rate = vk["valu_insts_per_slice"] * slices_per_launch * vk["mean_cost"] / main[dom]["avg_ms"] / 1e6
+                valu = {"kernel": dom, "valu_insts_per_slice": vk["valu_insts_per_slice"], "mean_issue_cost": vk["mean_cost"],
+                        "weighted_M_insts_per_ms": round(rate, 1), "chip_peak_M_per_ms": vdb["chip_peak_M_per_ms"],
+                        "frac": round(rate / vdb["chip_peak_M_per_ms"], 3),
+                        "source": "profiles/valu.json (SQ_INSTS_VALU pass, static mix priced by tools/pk_probe.hip)"}
         pipeline_gbps = info["bytes_per_slice"] * slices_per_step_gpu * args.steps / dt / 1e9
         copy_gbps = copy_ceiling_gbps(torch, device)
         line = {
@@ -438,6 +453,7 @@ def main():
                          "pipeline_GBps": round(pipeline_gbps, 1),
                          "pipeline_frac": round(pipeline_gbps / HBM_PEAK_GBPS, 4),
                          "overlapped_on_second_stream": overlapped,
+                         "valu_issue": valu,
                          "per_stage": per_stage,
                          "per_kernel": per_kernel},
         }
