@@ -8,6 +8,7 @@
 // There is NO CPU fallback: without a gfx950 device every constructor returns PV_ERR_NO_DEVICE.
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -1312,6 +1313,18 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
             for (int64_t t = t0; t < t1; ++t) cb.add(sl[(size_t)t], b->plan.out_frames, wden, wden_hi);
             // one workgroup per row leaves CUs idle below 256 rows: split the rows' slices into runs
             int runs_wanted = (256 + c.rows - 1) / c.rows;
+            if (c.rows > 256) {
+                // ... and a partly filled last round above them (320 rows: two rounds for 1.25 rounds of work): pick the
+                // run count with the best product of round occupancy and useful share of a run (each later run
+                // re-adds the frames that reach into its range).  320 rows: 4 runs, 11.8 -> 13.1 G samples/s.
+                const double warm = (double)c.d.N / (double)(c.d.min_shift > 0 ? c.d.min_shift : 1) + 1.0;
+                double best = 0.0;
+                for (int r = 1; r <= 8; ++r) {
+                    const double wgs = (double)c.rows * r / 256.0, len = (double)(t1 - t0) / r;
+                    const double eff = wgs / std::ceil(wgs) * (r == 1 ? 1.0 : len / (len + warm));
+                    if (eff > best + 1e-9) best = eff, runs_wanted = r;
+                }
+            }
             if (const char *e = getenv("AUDIOMOD_PV_CHAIN_RUNS")) runs_wanted = atoi(e);
             ch.cs_begin = (int64_t)cs.size();
             ch.run_begin = (int)run_off.size();
