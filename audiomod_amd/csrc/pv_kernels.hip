@@ -46,19 +46,21 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
-// princarg(a) = mod(a + pi, -2 pi) + pi with mod(x, y) = x - y*floor(x/y), in double (sys.h:84,91).
-// floor(x/y) needs the correctly rounded quotient only when x/y is within rounding distance of an integer;
-// otherwise floor(x * (1/y)) is the same integer (|x*(1/y) - x/y| <= 3.4e-16 |x/y|, far below the 1e-9
-// guard band), so the IEEE divide runs only on the rare lanes inside the guard band.  The returned value is
-// bit-identical to the reference expression in every case.
-__device__ __forceinline__ double princarg(double a) {
-    const double x = a + PV_PI;
+// princarg(a) = mod(a + pi, -2 pi) + pi with mod(x, y) = x - y*floor(x/y), in double (sys.h:84,91), for an argument
+// that is a FLOAT (every call site: the sum or difference of float phases, widened).  floor() needs the correctly
+// rounded quotient x / y; the divisor is a constant, so the quotient is formed without a division -- q0 = x (1 / y),
+// the exact residual r = x - y q0 (fma), q1 = q0 + r (1 / y) (fma) -- and q1 IS the IEEE quotient for every one of
+// the 2^32 float arguments: tests/native/host_princarg_all.cc compares it, and the function's result, with the
+// reference expression bit for bit on all of them.  Three dependent operations where the division is about ten:
+// this is the critical path of the rotation chain's step.
+__device__ __forceinline__ double princarg_f(const float af) {
+    const double x = (double)af + PV_PI;
     const double y = -2.0 * PV_PI;
-    const double q = x * (1.0 / y);
-    double n = floor(q);
-    const double f = q - n;
-    if (!(f > 1e-9 && f < 1.0 - 1e-9)) n = floor(x / y);
-    return (x - (y * n)) + PV_PI;
+    constexpr double inv_y = 1.0 / (-2.0 * PV_PI);
+    const double q0 = x * inv_y;
+    const double r = __builtin_fma(-y, q0, x);
+    const double q1 = __builtin_fma(r, inv_y, q0);
+    return (x - (y * floor(q1))) + PV_PI;
 }
 
 // atan2f's interval table (pv_atan2f.h) as the kernels read it into LDS
@@ -75,13 +77,6 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// the plain reference expression (one IEEE divide): lower latency when a single dependent chain is all there is
-__device__ __forceinline__ double princarg_div(double a) {
-    const double x = a + PV_PI;
-    const double y = -2.0 * PV_PI;
-    return (x - (y * floor(x / y))) + PV_PI;
 }
 
 // princarg where the argument is the sum or difference of two wrapped phases (|a| <= 2 pi + a few float ulp):
@@ -722,7 +717,7 @@ __device__ __forceinline__ void match_wave_role(const MatchArgs &a, const int ro
             const float a2 = a2v[u];
             const float a1 = splane >= 0 ? a1v[u] : 0.f;
             const float d1 = a2 - a1 - pomega;
-            const float pdelta = (float)((double)pomega + princarg((double)d1));
+            const float pdelta = (float)((double)pomega + princarg_f(d1));
             // region of p1 in the previous same-channel step = number of its boundaries <= p1
             const int w1 = p1 >> 6, b1 = p1 & 63;
             const unsigned long long le = b1 == 63 ? ~0ull : ((2ull << b1) - 1ull);
@@ -849,7 +844,7 @@ __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *
                 const float po_lock = (float)princarg_small((double)(r.a1 + rprev[r1]));
                 const float po_full = spo[p1];
                 const float po = kind == 2 ? po_lock : (kind == 1 ? po_full : 0.f);
-                const float tgt = (float)princarg_div((double)(po + r.adv));
+                const float tgt = (float)princarg_f(po + r.adv);
                 rtk[k] = (float)princarg_small((double)(tgt - r.a2));
             }
 #pragma unroll
@@ -880,7 +875,7 @@ __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *
                 if (kind == 2) po = (float)princarg_small((double)(r.a1 + rprev[r.p1r1 >> 16]));
                 else if (kind == 1) po = spo[r.p1r1 & 0xffffu];
                 else po = 0.f;
-                const float tgt = (float)princarg_div((double)(po + r.adv));
+                const float tgt = (float)princarg_f(po + r.adv);
                 const float rt = (float)princarg_small((double)(tgt - r.a2));
                 rcur[p] = rt;
                 a.rot[plane * a.PKP + p] = rt;
@@ -915,9 +910,9 @@ __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *
                     const float pp = Ap ? Ap[i] : 0.f;
                     const float omega = (float)((a.two_pi_hop * (double)i) / Nd);
                     const float d1 = phi - pp - omega;
-                    const float delta = (float)((double)omega + princarg((double)d1));
+                    const float delta = (float)((double)omega + princarg_f(d1));
                     const float advance = delta * pinc_f / hop_f;
-                    outv = (float)princarg((double)(po + advance));
+                    outv = (float)princarg_f(po + advance);
                 }
                 spo[i] = outv;
                 outp[i] = outv;
@@ -998,14 +993,14 @@ __device__ __forceinline__ void prop_role(const PropArgs &a, const int row, cons
         for (int u = 0; u < kU; ++u) {
             const int tl = tl0 + u < a.Tn ? tl0 + u : a.Tn - 1;
             const float d1 = phi[u] - (u ? phi[u - 1] : pp) - omega;
-            const float delta = (float)((double)omega + princarg((double)d1));
+            const float delta = (float)((double)omega + princarg_f(d1));
             adv[u] = delta * (float)a.phase_inc[tl] / hop_f;
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             if (tl0 + u >= a.Tn) break;
             // firstentry: only the very first step of the stream (function-static in the reference)
-            const float outv = (a.t0 + tl0 + u == 0 && c == 0) ? phi[u] : (float)princarg((double)(po + adv[u]));
+            const float outv = (a.t0 + tl0 + u == 0 && c == 0) ? phi[u] : (float)princarg_f(po + adv[u]);
             pp = phi[u];
             po = outv;
             op[plane[u] * a.HP + i] = outv;

@@ -75,3 +75,21 @@ def test_short_sincos_against_double(tmp_path):
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
     dev = open(os.path.join(ROOT, "audiomod_amd/csrc/pv_kernels.hip")).read()
     assert "pv_sincos_small(" in dev and "PV_SINCOS_MAX_ARG" in dev
+
+
+def test_division_free_princarg_on_every_float(tmp_path):
+    """princarg_f (pv_kernels.hip): the quotient of the reference's princarg formed with two fma's on the constant
+    reciprocal instead of an IEEE division -- every call site passes a float, so quotient and result are compared with
+    the reference expression on all 2^32 arguments (tests/native/host_princarg_all.cc; ~40 CPU-seconds, threaded)."""
+    exe = str(tmp_path / "host_princarg_all")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-pthread",
+                    os.path.join(ROOT, "tests/native/host_princarg_all.cc"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 result mismatches, 0 quotient mismatches" in r.stdout, r.stdout + r.stderr
+    dev = open(os.path.join(ROOT, "audiomod_amd/csrc/pv_kernels.hip")).read()
+    for line in ("const double q0 = x * inv_y;", "const double r = __builtin_fma(-y, q0, x);",
+                 "const double q1 = __builtin_fma(r, inv_y, q0);", "return (x - (y * floor(q1))) + PV_PI;",
+                 "constexpr double inv_y = 1.0 / (-2.0 * PV_PI);"):
+        assert line in dev, line
+    code = "\n".join(ln.split("//")[0] for ln in dev.splitlines())
+    assert "princarg_div(" not in code and " princarg(" not in code  # no other wrap of an unbounded argument is left
