@@ -826,8 +826,10 @@ __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *
 #pragma unroll
             for (int k = 0; k < kK; ++k) rk[k] = qk[k];
             if (tl + 1 < a.Tn) { // uniform branch
+#if !(defined(PV_EXP_SEQ) && (PV_EXP_SEQ & 16))
                 h0 = ld_hdr(tl + 1);
                 ld_recs(tl + 1, qk);
+#endif
             } else {
                 h0 = 3u; // sentinel: leaves both loops
             }
@@ -841,23 +843,43 @@ __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *
                 const PeakRec r = rk[k];
                 const uint32_t r1 = min(r.p1r1 >> 16, (uint32_t)(a.PKP - 1));
                 const uint32_t p1 = (r.p1r1 & 0xffffu) & (uint32_t)(hs - 1);
+                // (PV_EXP_SEQ: elimination builds for timing only -- tools/build_variant.sh, tools/seq_elim.sh -- bit 0 no
+                // princarg_small, 1 no princarg_f, 2 no global store, 3 no barrier, 4 no record prefetch)
+#if defined(PV_EXP_SEQ) && (PV_EXP_SEQ & 1)
+                const float po_lock = r.a1 + rprev[r1];
+#else
                 const float po_lock = (float)princarg_small((double)(r.a1 + rprev[r1]));
+#endif
                 const float po_full = spo[p1];
                 const float po = kind == 2 ? po_lock : (kind == 1 ? po_full : 0.f);
+#if defined(PV_EXP_SEQ) && (PV_EXP_SEQ & 2)
+                const float tgt = po + r.adv;
+#else
                 const float tgt = (float)princarg_f(po + r.adv);
+#endif
+#if defined(PV_EXP_SEQ) && (PV_EXP_SEQ & 1)
+                rtk[k] = tgt - r.a2;
+#else
                 rtk[k] = (float)princarg_small((double)(tgt - r.a2));
+#endif
             }
 #pragma unroll
             for (int k = 0; k < kK; ++k) {
                 rcur[rixk[k]] = rtk[k];
+#if !(defined(PV_EXP_SEQ) && (PV_EXP_SEQ & 4))
                 a.rot[plane * a.PKP + rixk[k]] = rtk[k];
+#endif
             }
             kind = 2;
             float *tmp = rprev;
             rprev = rcur;
             rcur = tmp;
             ++tl;
+#if defined(PV_EXP_SEQ) && (PV_EXP_SEQ & 8)
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0) only: no barrier (timing experiment)
+#else
             __syncthreads();
+#endif
         }
         if (tl >= a.Tn) break;
         // ---- general step (first slice, no-peak steps, or more peaks than lanes)
