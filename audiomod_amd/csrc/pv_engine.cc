@@ -32,6 +32,13 @@ static int hip_fail(hipError_t e, const char *what, int line) {
     g_last_error = buf;
     return PV_ERR_HIP;
 }
+// inside Core::launch_chunk (returns nothing): the first failing call of a launch sequence is remembered with its line
+// and reported by the entry point that enqueued it (pv_batch_run / pv_feed)
+#define HIPV(call)                                                           \
+    do {                                                                     \
+        hipError_t e__ = (call);                                             \
+        if (e__ != hipSuccess && launch_err == hipSuccess) launch_err = e__, launch_err_line = __LINE__; \
+    } while (0)
 #define HIPC(call)                                                 \
     do {                                                           \
         hipError_t e__ = (call);                                   \
@@ -78,7 +85,11 @@ template <typename T> struct DevBuf {
         // count), but "provably unused" deserves a belt: with this, what such a slot holds cannot depend on what the
         // memory held before -- round 2 saw one bit-identity test fail twice, with identical garbage in one output
         // sample, on what was probably one box of the pool, and never again.
+#ifdef PV_POISON // debugging build: NaN / -1 patterns, so that relying on these zeros shows (pv_kernels.hip PV_POISON)
+        HIPC(hipMemset(p, 0xFF, (count ? count : 1) * sizeof(T)));
+#else
         HIPC(hipMemset(p, 0, (count ? count : 1) * sizeof(T)));
+#endif
         return PV_OK;
     }
     int upload(const std::vector<T> &v) {
@@ -296,7 +307,16 @@ struct Core {
     bool three_stage = false; // pipelined batch path: resampling of chunk i-2 between the front of i and the fused kernel of i-1
     int chain_AR = 0, chain_smask = 0, chain_waves = 0;
     int chain_max_adv = 0; // set before init(): the largest overlap-add advance the planner can emit
-    DevBuf<float> st_acc, stream; // accumulator-ring images; normalised overlap-add stream rings (resampling only)
+    DevBuf<float> st_acc, stream; // accumulator-ring images (two halves); normalised overlap-add stream rings (resampling only)
+    mutable int acc_half = 0;     // which half of st_acc the next fused launch reads
+    mutable hipError_t launch_err = hipSuccess; // first HIP failure inside launch_chunk since take_launch_error()
+    mutable int launch_err_line = 0;
+    int take_launch_error() const {
+        if (launch_err == hipSuccess) return PV_OK;
+        const int rc = hip_fail(launch_err, "a launch / event call of Core::launch_chunk", launch_err_line);
+        launch_err = hipSuccess;
+        return rc;
+    }
     // resample tiles (outputs [ka, kb)) of the fused path
     void build_res_tiles(int64_t ka, int64_t kb, std::vector<ResTile> &tiles, std::vector<uint2> &otab) const;
     static bool chain_wanted() {
@@ -541,7 +561,7 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     if (!(use_chain && wave_fft()))
         if ((st = frames.alloc((size_t)rows * FR * d.N)) != PV_OK) return st;
     if (use_chain) {
-        if ((st = st_acc.alloc((size_t)rows * chain_AR)) != PV_OK) return st;
+        if ((st = st_acc.alloc(2 * (size_t)rows * chain_AR)) != PV_OK) return st; // read half + written half, swapped per launch
         if (d.resample)
             if ((st = stream.alloc((size_t)rows * ((size_t)chain_smask + 1))) != PV_OK) return st;
     }
@@ -572,6 +592,7 @@ int Core::reset_state(hipStream_t st) {
     if (st_po.p) HIPC(hipMemsetAsync(st_po.p, 0, st_po.n * sizeof(float), st));
     if (st_kind.p) HIPC(hipMemsetAsync(st_kind.p, 0, st_kind.n * sizeof(int32_t), st));
     if (st_acc.p) HIPC(hipMemsetAsync(st_acc.p, 0, st_acc.n * sizeof(float), st));
+    acc_half = 0;
     return PV_OK;
 }
 
@@ -741,21 +762,21 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder;
     const int cm = bypass ? -1 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
     auto rec = [&](int i) {
-        if (ev) (void)hipEventRecord(ev[i], st);
+        if (ev) HIPV(hipEventRecord(ev[i], st));
     };
     // the phase stage's latency-bound kernel: on `st` (part 0), or handed to the second stream after what the
     // main stream has launched so far (part 1) and waited for before what follows (part 2)
     auto side_stream = [&](int k, auto &&launch_on) {
         if (defer_chain) return;
         if (part == 1) {
-            (void)hipEventRecord(ev_match, st);
-            (void)hipStreamWaitEvent(st_chain, ev_match, 0);
-            if (ev) (void)hipEventRecord(ev[2 * k], st_chain);
+            HIPV(hipEventRecord(ev_match, st));
+            HIPV(hipStreamWaitEvent(st_chain, ev_match, 0));
+            if (ev) HIPV(hipEventRecord(ev[2 * k], st_chain));
             launch_on(st_chain);
-            if (ev) (void)hipEventRecord(ev[2 * k + 1], st_chain);
-            (void)hipEventRecord(ev_chain, st_chain);
+            if (ev) HIPV(hipEventRecord(ev[2 * k + 1], st_chain));
+            HIPV(hipEventRecord(ev_chain, st_chain));
         } else if (part == 2) {
-            if (!only_resample) (void)hipStreamWaitEvent(st, ev_chain, 0);
+            if (!only_resample) HIPV(hipStreamWaitEvent(st, ev_chain, 0));
         } else {
             rec(2 * k);
             launch_on(st);
@@ -780,7 +801,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     aa.npk = npk.p;
     if (front && !only_chain) rec(2 * PV_K_ANALYZE);
     if (single_launch) fused.aa = aa;
-    else if (front && !only_chain) launch_analyze(aa, st);
+    else if (front && !only_chain) launch_analyze(aa, st); HIPV(hipGetLastError());
     if (front && !only_chain && d.vocoder && carrier) {
         // the carrier is one more (data-independent) row: same analysis, its own planes
         AnalyzeArgs ca = aa;
@@ -789,7 +810,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ca.find_peaks = 0;
         ca.mag = cmag.p;
         ca.phase = cphase.p;
-        launch_analyze(ca, st);
+        launch_analyze(ca, st); HIPV(hipGetLastError());
     }
     if (front && !only_chain) rec(2 * PV_K_ANALYZE + 1);
 
@@ -815,7 +836,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ma.modes = modes.p;
         if (front && !only_chain) rec(2 * PV_K_MATCH);
         if (single_launch) fused.ma = ma;
-        else if (front && !only_chain) launch_match(ma, st);
+        else if (front && !only_chain) launch_match(ma, st); HIPV(hipGetLastError());
         if (front && !only_chain) rec(2 * PV_K_MATCH + 1);
         SeqArgs qa{};
         qa.N = d.N;
@@ -854,7 +875,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
             qa.narrow = narrow;
         }
         if (single_launch) fused.qa = qa;
-        else side_stream(PV_K_SEQ, [&](hipStream_t s) { launch_seq(qa, s); });
+        else side_stream(PV_K_SEQ, [&](hipStream_t s) { launch_seq(qa, s); HIPV(hipGetLastError()); });
     } else if (cm == 0) {
         PropArgs pa{};
         pa.N = d.N;
@@ -874,7 +895,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         pa.st_pp = st_pp.p;
         pa.st_po = st_po.p;
         if (single_launch) fused.pa = pa;
-        else side_stream(PV_K_PROP, [&](hipStream_t s) { launch_prop(pa, s); });
+        else side_stream(PV_K_PROP, [&](hipStream_t s) { launch_prop(pa, s); HIPV(hipGetLastError()); });
     }
 
     SynthArgs sa{};
@@ -921,7 +942,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ca.mag = mag.p;
         if (back) rec(2 * PV_K_CEPSTRAL);
         if (single_launch) fused.ca = ca;
-        else if (back) launch_cepstral(ca, st);
+        else if (back) launch_cepstral(ca, st); HIPV(hipGetLastError());
         if (back) rec(2 * PV_K_CEPSTRAL + 1);
     }
     if (chain && !single_launch) {
@@ -935,18 +956,25 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ca.smask = chain_smask;
         ca.waves = chain_waves;
         {
+#ifdef PV_DIAG
             static const int diag = [] {
                 const char *e = getenv("AUDIOMOD_PV_CHAIN_DIAG");
                 return e ? atoi(e) : 0;
             }();
             ca.diag = diag;
+#endif
         }
         ca.slices = chain->slices;
         ca.run_off = chain->run_off;
         ca.runs = chain->runs;
         ca.wden = chain->wden;
         ca.wden_hi = chain->wden_hi;
-        ca.st_acc = st_acc.p;
+        // the ring images: this launch reads one half and writes the other (ChainArgs::st_acc_in); launches are
+        // enqueued in slice order on one stream, so flipping at enqueue time is flipping in execution order
+        ca.st_acc_in = st_acc.p + (size_t)acc_half * rows * chain_AR;
+        ca.st_acc_out = st_acc.p + (size_t)(acc_half ^ 1) * rows * chain_AR;
+        ca.fresh = t0 == 0 ? 1 : 0;
+        if (!only_resample) acc_half ^= 1;
         ca.stream = stream.p;
         ca.resample = d.resample ? 1 : 0;
         ca.out = chain->out;
@@ -975,39 +1003,39 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ra.out_stride_row = out_stride_row;
         ra.k_base = k_base;
         if (d.resample && chain->res_stream && chain->ev_ring_free && !only_resample)
-            (void)hipStreamWaitEvent(st, chain->ev_ring_free, 0);
+            HIPV(hipStreamWaitEvent(st, chain->ev_ring_free, 0));
         if (only_resample) {
         } else if (wave_fft()) {
             // synthesis and overlap-add in one kernel: the frames stay in LDS
             rec(2 * PV_K_SYNTH_OLA);
-            launch_synth_chain(sa, ca, st);
+            launch_synth_chain(sa, ca, st); HIPV(hipGetLastError());
             rec(2 * PV_K_SYNTH_OLA + 1);
         } else {
             rec(2 * PV_K_SYNTH);
-            launch_synth(sa, st);
+            launch_synth(sa, st); HIPV(hipGetLastError());
             rec(2 * PV_K_SYNTH + 1);
             rec(2 * PV_K_OLA_RESAMPLE);
-            launch_frames_chain(ca, st);
+            launch_frames_chain(ca, st); HIPV(hipGetLastError());
             if (!d.resample || no_resample) rec(2 * PV_K_OLA_RESAMPLE + 1);
         }
         if (no_resample) return;
         if (d.resample && chain->res_stream) {
-            (void)hipEventRecord(chain->ev_fused, st);
-            (void)hipStreamWaitEvent(chain->res_stream, chain->ev_fused, 0);
-            if (ev && wave_fft()) (void)hipEventRecord(ev[2 * PV_K_OLA_RESAMPLE], chain->res_stream);
-            launch_resample(ra, chain->res_stream);
-            if (ev) (void)hipEventRecord(ev[2 * PV_K_OLA_RESAMPLE + 1], chain->res_stream);
-            (void)hipEventRecord(chain->ev_res, chain->res_stream);
+            HIPV(hipEventRecord(chain->ev_fused, st));
+            HIPV(hipStreamWaitEvent(chain->res_stream, chain->ev_fused, 0));
+            if (ev && wave_fft()) HIPV(hipEventRecord(ev[2 * PV_K_OLA_RESAMPLE], chain->res_stream));
+            launch_resample(ra, chain->res_stream); HIPV(hipGetLastError());
+            if (ev) HIPV(hipEventRecord(ev[2 * PV_K_OLA_RESAMPLE + 1], chain->res_stream));
+            HIPV(hipEventRecord(chain->ev_res, chain->res_stream));
         } else if (d.resample) {
             if (wave_fft() || only_resample) rec(2 * PV_K_OLA_RESAMPLE);
-            launch_resample(ra, st);
+            launch_resample(ra, st); HIPV(hipGetLastError());
             rec(2 * PV_K_OLA_RESAMPLE + 1);
         }
         return;
     }
     if (back) rec(2 * PV_K_SYNTH);
     if (single_launch) fused.sa = sa;
-    else if (back) launch_synth(sa, st);
+    else if (back) launch_synth(sa, st); HIPV(hipGetLastError());
     if (back) rec(2 * PV_K_SYNTH + 1);
 
     OlaArgs oa{};
@@ -1041,10 +1069,10 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         fused.oa = oa;
         fused.coremode = cm;
         fused.cepstral = d.cepstral ? 1 : 0;
-        launch_stream(fused, st);
+        launch_stream(fused, st); HIPV(hipGetLastError());
     } else if (back && ntiles > 0) {
         rec(2 * PV_K_OLA_RESAMPLE);
-        launch_ola(oa, st);
+        launch_ola(oa, st); HIPV(hipGetLastError());
         rec(2 * PV_K_OLA_RESAMPLE + 1);
     }
 }
@@ -1530,6 +1558,7 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
     if (b->res_stream && c.use_chain) // the caller synchronises `st`: it has to cover the resampling stream too
         for (size_t ci = nchunks > 2 ? nchunks - 2 : 0; ci < nchunks; ++ci)
             HIPC(hipStreamWaitEvent(st, b->ev_res[ci & 3], 0));
+    if ((rc = c.take_launch_error()) != PV_OK) return rc;
     HIPC(hipGetLastError());
     return PV_OK;
 }
@@ -1815,6 +1844,7 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
                        reinterpret_cast<const float *>(e->d_desc.p + o_c), e->d_whisper.p,
                        c.d.vocoder ? &car : nullptr, e->d_out.p, e->out_cap, ka, e->stream, nullptr, 0, nullptr, nullptr,
                        nullptr, c.can_single_launch(), c.use_chain ? &cl : nullptr);
+        if ((st = c.take_launch_error()) != PV_OK) return fail(st);
         const int64_t cnt = kb - ka;
         hipError_t he = hipSuccess;
         if (cnt > 0)

@@ -223,7 +223,14 @@ struct ChainArgs {
     const ChainSlice *slices; // run lists, concatenated
     const float *wden;        // denominators, indexed wden_off + quad-relative sample
     const float *wden_hi;     // ... for channels > 0 (differs from wden only after a CONSTANT-mode overrun)
-    float *st_acc;            // [rows][AR] ring image carried between launches
+    // Ring image carried between launches.  Run 0 of a row reads st_acc_in, the row's LAST run writes st_acc_out, and
+    // the two are different buffers (the engine swaps them per launch): with one buffer, the last run's workgroup
+    // could overwrite the image before a late-starting run 0 of the same launch had read it (nothing orders the
+    // workgroups of one launch).  fresh: the launch starts the stream (slice 0) -- the accumulator is all zeros by
+    // definition (channelinfo.cc:93-115) and nothing is read.
+    const float *st_acc_in;   // [rows][AR]
+    float *st_acc_out;        // [rows][AR]
+    int fresh;
     float *stream;            // [rows][smask + 1] normalised overlap-add stream (resampling configurations)
     int resample;
     // output (not resampling)

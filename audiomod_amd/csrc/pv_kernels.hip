@@ -35,6 +35,22 @@
 
 namespace pv {
 
+// -DPV_POISON (a debugging build, tools/build_variant.sh poison -DPV_POISON): every kernel first fills its whole
+// dynamic LDS with a NaN pattern, and the engine fills every device buffer with 0xFF bytes instead of zeros, so that a
+// read of anything the code did not write itself shows up in the output deterministically instead of depending on what
+// the CU or the memory held before.  The product build contains none of this.
+#ifdef PV_POISON
+__device__ __forceinline__ void pv_poison_lds(char *base) {
+    const uint32_t bytes = ((const __attribute__((address_space(4))) uint32_t *)__builtin_amdgcn_dispatch_ptr())[7]; // group_segment_size
+    const int nt = blockDim.x * blockDim.y * blockDim.z, tid = threadIdx.x;
+    for (uint32_t i = tid; i < bytes / 4; i += nt) reinterpret_cast<uint32_t *>(base)[i] = 0x7fc0dead;
+    __syncthreads();
+}
+#define PV_POISON_LDS(base) pv_poison_lds(base)
+#else
+#define PV_POISON_LDS(base) ((void)0)
+#endif
+
 #define PV_PI 3.14159265358979323846
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -166,6 +182,7 @@ __device__ __forceinline__ bool is_peak(const float *smag, int b, int hs) {
 
 __global__ __launch_bounds__(kFftThreads) void pv_analyze_kernel(const AnalyzeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
     const DevTables &tb = a.tb;
     const int N = tb.N, hs = tb.hs, nc = tb.nc, nt = blockDim.x;
     float2 *buf = reinterpret_cast<float2 *>(smem_raw); // [nc]
@@ -536,6 +553,7 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
 // slower: 1.05 vs 0.91 ms per 64 K slices)
 template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyze_wave_kernel(const AnalyzeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
     cf *lds = reinterpret_cast<cf *>(smem_raw) + (threadIdx.x >> 6) * WF<NC>::LDS_CF;
     int row, tl;
     if (!block_to_row_slice_w<WPB>(a.Tn, a.rows, row, tl)) return; // wave-uniform
@@ -734,6 +752,7 @@ __device__ __forceinline__ void match_wave_role(const MatchArgs &a, const int ro
 
 __global__ __launch_bounds__(kMatchThreads) void pv_match_kernel(const MatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
     const int wave = threadIdx.x >> 6;
     const int tl = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
     if (tl >= a.Tn) return; // wave-uniform
@@ -954,6 +973,7 @@ __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *
 
 template <int kK> __global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
     // the chain is pure latency and may share the GPU with the overlap-add tiles of the previous chunk (second
     // HIP stream): let its few waves win every issue arbitration
     if (a.high_prio) __builtin_amdgcn_s_setprio(3);
@@ -1063,6 +1083,7 @@ __device__ __forceinline__ float vocoder_mag(const float *__restrict__ mod, cons
 
 __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
     const DevTables &tb = a.tb;
     const int N = tb.N, hs = tb.hs, nc = tb.nc, nt = blockDim.x;
     float2 *buf = reinterpret_cast<float2 *>(smem_raw);        // [nc]
@@ -1579,6 +1600,7 @@ template <int NC, int WPB, int kPlainCore = -1>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(NC == 1024 ? 4 : 1))) void
 pv_synth_wave_kernel(const SynthArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
     cf *lds = reinterpret_cast<cf *>(smem_raw) + (threadIdx.x >> 6) * WF<NC>::LDS_CF;
     int row, tl;
     if (!block_to_row_slice_w<WPB>(a.Tn, a.rows, row, tl)) return; // wave-uniform
@@ -1835,6 +1857,7 @@ __device__ __forceinline__ void cepstral_wave_role(const CepstralArgs &a, const 
 
 template <int NC> __global__ __launch_bounds__(64) void pv_cepstral_wave_kernel(const CepstralArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
     int row, tl;
     if (!block_to_row_slice_w<1>(a.Tn, a.rows, row, tl)) return; // wave-uniform
     cepstral_wave_role<NC>(a, row, tl, reinterpret_cast<cf *>(smem_raw));
@@ -1845,6 +1868,7 @@ template <int NC> __global__ __launch_bounds__(64) void pv_cepstral_wave_kernel(
 // (phasevocoderprocess.cc:925-999), which is size-agnostic.
 __global__ __launch_bounds__(kFftThreads) void pv_cepstral_kernel(const CepstralArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
     const DevTables &tb = a.tb;
     const int hs = tb.hs, nc = tb.nc, nt = blockDim.x;
     constexpr int kCut = 60;
@@ -2135,6 +2159,7 @@ constexpr int kOlaRows = 2; // rows per workgroup of the batch / streaming overl
 
 template <int kRes> __global__ __launch_bounds__(kTileOut) void pv_ola_kernel(const OlaArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
     ola_role<kOlaRows, kRes>(a, blockIdx.x, blockIdx.y * kOlaRows, smem_raw);
 }
 
@@ -2177,6 +2202,14 @@ __device__ __forceinline__ float dpp_ror1(float v) { // lane i <- lane i - 1, la
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xf, 0xf, false));
 }
 
+// Measurement switches of the fused kernel (tools/chain_diag.sh: parts switched off, results meaningless) exist only in
+// builds made with -DPV_DIAG (tools/build_variant.sh); the product library has none of them.
+#ifdef PV_DIAG
+#define PV_CHAIN_DIAG(c, bit) (((c).diag & (bit)) != 0)
+#else
+#define PV_CHAIN_DIAG(c, bit) false
+#endif
+
 struct ChainLds {
     float *acc;   // [AR]
     int *turn;    // next slice whose frame may be added
@@ -2196,9 +2229,10 @@ __host__ __device__ inline size_t chain_shared_bytes(const ChainArgs &c) {
 // by re-adding the frames before it, ChainSlice flag bit 1)
 __device__ __forceinline__ void chain_prologue(const ChainArgs &c, const ChainLds &l, int row, bool first_run = true) {
     const int nt = blockDim.x, tid = threadIdx.x;
-    const float4 *sa = reinterpret_cast<const float4 *>(c.st_acc + (int64_t)row * c.AR);
+    const float4 *sa = reinterpret_cast<const float4 *>(c.st_acc_in + (int64_t)row * c.AR);
+    const bool carried = first_run && !c.fresh; // (a stream's first launch starts from the empty accumulator)
     for (int i = tid; i < c.AR / 4; i += nt)
-        reinterpret_cast<float4 *>(l.acc)[i] = first_run ? sa[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4 *>(l.acc)[i] = carried ? sa[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid == 0) *l.turn = 0;
     __syncthreads();
 }
@@ -2206,7 +2240,7 @@ __device__ __forceinline__ void chain_epilogue(const ChainArgs &c, const ChainLd
     __syncthreads(); // every wave has passed its last turn
     if (!last_run) return; // only the run that ends the launch holds the row's true accumulator
     const int nt = blockDim.x, tid = threadIdx.x;
-    float4 *sa = reinterpret_cast<float4 *>(c.st_acc + (int64_t)row * c.AR);
+    float4 *sa = reinterpret_cast<float4 *>(c.st_acc_out + (int64_t)row * c.AR);
     for (int i = tid; i < c.AR / 4; i += nt) sa[i] = reinterpret_cast<const float4 *>(l.acc)[i];
 }
 
@@ -2315,7 +2349,7 @@ __device__ __forceinline__ void chain_finish_slice(const ChainArgs &c_in, const 
             out[i] = y;
         }
     };
-    if (!(c.diag & 2)) {
+    if (!PV_CHAIN_DIAG(c, 2)) {
         // (all reads, then the divisions, then the writes: this is still inside the turn)
         float v[4];
 #pragma unroll
@@ -2433,11 +2467,14 @@ __device__ __forceinline__ void chain_slice_tail(const ChainArgs &c_in, const Ch
     // assembly -- left free, the compiler may put the compare right in front of it (seen as a rare wrong write-back:
     // test_fused_overlap_add_is_bit_identical_to_the_tile_path failed once in four full runs).  With the compares
     // forced to this side of the wait loop, the loop's own instructions are the distance.
+    // The s_nop inside the pin makes the distance part of the instruction stream rather than a property of what the
+    // compiler happens to schedule behind it: every compare that produced a mask is in front of this statement (the
+    // masks are its operands), every masked() behind it.
 #pragma unroll
     for (int j = 0; j < NM; ++j)
-        asm volatile("" : "+s"(zero_at[j][0]), "+s"(zero_at[j][1]), "+s"(zero_at[j][2]), "+s"(zero_at[j][3]));
+        asm volatile("s_nop 1 ; pvpin" : "+s"(zero_at[j][0]), "+s"(zero_at[j][1]), "+s"(zero_at[j][2]), "+s"(zero_at[j][3]));
     // ---- the turn
-    if (!(c.diag & 4)) chain_wait_turn(l.turn, tl);
+    if (!PV_CHAIN_DIAG(c, 4)) chain_wait_turn(l.turn, tl);
     __builtin_amdgcn_s_setprio(3); // the turn's instructions ahead of the three other waves of this SIMD
     float4 V[NS];
     if (!skip) {
@@ -2491,6 +2528,7 @@ template <int NC, int kPlainCore, int kRes>
 __global__ __launch_bounds__(NC == 1024 ? ((kPlainCore < 0 || kPlainCore == 3) ? 768 : 1024) : 512) void pv_synth_chain_kernel(
     const SynthArgs s, const ChainArgs c) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
     using W = WF<NC>;
     constexpr int N = 2 * NC, hs = NC, NQ = N / 4, NP = NQ / 64;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -2514,7 +2552,7 @@ __global__ __launch_bounds__(NC == 1024 ? ((kPlainCore < 0 || kPlainCore == 3) ?
         const bool skip = (sl.flags & 1) && upper; // wave-uniform
         float4 A[NP];
         if (!skip) {
-            if (!(c.diag & 8)) synth_wave_role<NC, kPlainCore, 1>(s, row, tl, wlds, lane);
+            if (!PV_CHAIN_DIAG(c, 8)) synth_wave_role<NC, kPlainCore, 1>(s, row, tl, wlds, lane);
             // ifftshift + synthesis window (phasevocoderimpl.h:183-198): four consecutive samples per lane and piece
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
@@ -2538,6 +2576,7 @@ __global__ __launch_bounds__(NC == 1024 ? ((kPlainCore < 0 || kPlainCore == 3) ?
 // from there, up to eight pieces (2048 samples) at a time.
 template <int kRes> __global__ __launch_bounds__(1024) void pv_frames_chain_kernel(const ChainArgs c) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = blockIdx.x, run = blockIdx.y;
     const int i_begin = c.run_off[run], i_count = c.run_off[run + 1] - i_begin;
@@ -2641,6 +2680,7 @@ constexpr int kResRows = 4; // rows per workgroup of the resampling kernel: a ta
 template <int kRes> // 1 = direct sinc table, 2 = cubic-interpolated table
 __global__ __launch_bounds__(kTileOut) void pv_resample_kernel(const ResArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
     constexpr int NR = kResRows;
     float4 *tab4 = reinterpret_cast<float4 *>(smem_raw);
     float *stab = reinterpret_cast<float *>(smem_raw);
@@ -2760,6 +2800,7 @@ __device__ __forceinline__ void stage_handoff() {
 
 template <int NC> __global__ __launch_bounds__(kStreamThreads) void pv_stream_kernel(const StreamArgs s) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = kStreamThreads / 64;
     const int Tn = s.aa.Tn, rows = s.aa.rows, work = rows * Tn;
     cf *wlds = reinterpret_cast<cf *>(smem_raw) + wave * WF<NC>::LDS_CF;

@@ -568,23 +568,22 @@ for kw in (dict(semitones=4.0), dict(semitones=-7.0, mode="formant_pitchshift"),
            dict(mode="vocoder"), dict(mode="constant", semitones=-4.0)):
     kw = dict(kw); flush = kw.pop("flush", True)
     b = E.Batch(3, 40000, channels=2, flush=flush, **kw)
-    o = b.run(torch.from_numpy(x).cuda()); torch.cuda.synchronize()
+    xin = torch.from_numpy(x).cuda()
+    o = b.run(xin, d_out=torch.full((3, 2, b.out_frames), float("nan"), device="cuda"))  # an unwritten sample shows
+    torch.cuda.synchronize()
     outs.append(o.cpu().numpy()); b.close()
     g, _ = E.run_offline(x[1], flush=flush, block=777, **kw)
     outs.append(g)
 np.savez(sys.argv[1], *outs)
 """ % (ROOT,)
-    def both_paths(d, attempt):
+    def both_paths(d):
         files = []
         for tag, env in (("fused", {"AUDIOMOD_PV_FUSED": "2"}), ("tiles", {"AUDIOMOD_PV_FUSED": "0"})):
-            f = os.path.join(d, f"{tag}{attempt}.npz")
+            f = os.path.join(d, f"{tag}.npz")
             r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,
                                env=dict(os.environ, **env), timeout=900)
             assert r.returncode == 0, r.stdout + r.stderr
             files.append(np.load(f))
-            if os.environ.get("AUDIOMOD_PV_KEEP_NPZ"):  # debugging aid: keep what was compared
-                import shutil
-                shutil.copy(f, os.path.join(os.environ["AUDIOMOD_PV_KEEP_NPZ"], f"{tag}{attempt}.npz"))
         return files
 
     def mismatches(a, b):
@@ -593,23 +592,23 @@ np.savez(sys.argv[1], *outs)
         return bad
 
     with tempfile.TemporaryDirectory() as d:
-        a, b = both_paths(d, 0)
+        a, b = both_paths(d)
         assert len(a.files) == len(b.files) == 22
         bad = mismatches(a, b)
         if bad:
-            # Round 2 saw this comparison fail three times in ~30 suite runs (one output array differing in a few
-            # samples; different arrays; never when the test ran alone, never reproduced in 15 targeted runs, every
-            # array of every run within 1e-8 RMS of the oracle) -- see DESIGN.md section 7, open issues.  A mismatch
-            # that does not repeat is reported as an expected-failure with its details, one that repeats fails.
+            # Keep what differed where it survives the run (gpurun merges gpurun_out/ back): both arrays of every
+            # differing pair and the positions -- round 2 lost three occurrences of a rare mismatch to a temp directory.
+            keep = os.path.join(ROOT, "gpurun_out", "fused_vs_tiles_mismatch")
+            os.makedirs(keep, exist_ok=True)
             where = {}
             for k in bad:
                 if k.startswith("arr_"):
                     m = np.argwhere(a[k].view(np.uint32) != b[k].view(np.uint32))
-                    where[k] = (len(m), m[:3].tolist(), [(float(a[k][tuple(i)]), float(b[k][tuple(i)])) for i in m[:3]])
-            a2, b2 = both_paths(d, 1)
-            bad2 = mismatches(a2, b2)
-            assert not bad2, ("persistent mismatch between the fused and the tile path", bad, where, bad2)
-            pytest.xfail(f"transient fused / tile mismatch, not repeated on the second run: {bad} {where}")
+                    where[k] = (len(m), m[:8].tolist(), [(float(a[k][tuple(i)]), float(b[k][tuple(i)])) for i in m[:8]])
+                    np.savez(os.path.join(keep, k + ".npz"), fused=a[k], tiles=b[k], positions=m)
+            with open(os.path.join(keep, "where.txt"), "w") as fh:
+                fh.write(repr((bad, where)))
+            pytest.fail(f"fused and tile path differ: {bad} {where}")
 
 
 def test_short_square_root_is_correctly_rounded_on_every_float_of_its_range():
