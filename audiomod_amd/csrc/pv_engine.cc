@@ -309,6 +309,15 @@ struct Core {
     int chain_max_adv = 0; // set before init(): the largest overlap-add advance the planner can emit
     DevBuf<float> st_acc, stream; // accumulator-ring images (two halves); normalised overlap-add stream rings (resampling only)
     mutable int acc_half = 0;     // which half of st_acc the next fused launch reads
+#ifdef PV_DIAG
+    static bool debug_stale_acc() {
+        static const bool on = [] {
+            const char *e = getenv("AUDIOMOD_PV_DEBUG_STALE_ACC");
+            return e && atoi(e) != 0;
+        }();
+        return on;
+    }
+#endif
     mutable hipError_t launch_err = hipSuccess; // first HIP failure inside launch_chunk since take_launch_error()
     mutable int launch_err_line = 0;
     int take_launch_error() const {
@@ -591,6 +600,9 @@ int Core::reset_state(hipStream_t st) {
     if (st_pp.p) HIPC(hipMemsetAsync(st_pp.p, 0, st_pp.n * sizeof(float), st));
     if (st_po.p) HIPC(hipMemsetAsync(st_po.p, 0, st_po.n * sizeof(float), st));
     if (st_kind.p) HIPC(hipMemsetAsync(st_kind.p, 0, st_kind.n * sizeof(int32_t), st));
+#ifdef PV_DIAG
+    if (debug_stale_acc()) return PV_OK;
+#endif
     if (st_acc.p) HIPC(hipMemsetAsync(st_acc.p, 0, st_acc.n * sizeof(float), st));
     acc_half = 0;
     return PV_OK;
@@ -975,6 +987,15 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ca.st_acc_out = st_acc.p + (size_t)(acc_half ^ 1) * rows * chain_AR;
         ca.fresh = t0 == 0 ? 1 : 0;
         if (!only_resample) acc_half ^= 1;
+#ifdef PV_DIAG
+        // AUDIOMOD_PV_DEBUG_STALE_ACC=1 (diagnostic builds): recreate round 2's hazard on purpose -- one buffer for both
+        // directions and a first launch that reads it -- to see what a run 0 that starts from the previous pass's final
+        // accumulator image puts out (reset_state leaves the image alone under the same switch)
+        if (debug_stale_acc()) {
+            ca.st_acc_in = ca.st_acc_out = st_acc.p;
+            ca.fresh = 0;
+        }
+#endif
         ca.stream = stream.p;
         ca.resample = d.resample ? 1 : 0;
         ca.out = chain->out;
