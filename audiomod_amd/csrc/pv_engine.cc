@@ -304,6 +304,8 @@ struct Core {
     // 12.2 -- below a full chip's worth of rows the rotation chain's serial latency dominates either way, and the
     // tile path's kernels need no warm-up)
     static constexpr int kChainMinRows = 192;
+    bool fast_arith = false;  // set before init() by the batch engine (audiomod_pv.h PV_ARITH_FAST); only the fused
+                              // wave-FFT path has the fast kernels, everything else computes exactly either way
     bool three_stage = false; // pipelined batch path: resampling of chunk i-2 between the front of i and the fused kernel of i-1
     int chain_AR = 0, chain_smask = 0, chain_waves = 0;
     int chain_max_adv = 0; // set before init(): the largest overlap-add advance the planner can emit
@@ -983,18 +985,14 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ca.wden_hi = chain->wden_hi;
         // the ring images: this launch reads one half and writes the other (ChainArgs::st_acc_in); launches are
         // enqueued in slice order on one stream, so flipping at enqueue time is flipping in execution order
-        ca.st_acc_in = st_acc.p + (size_t)acc_half * rows * chain_AR;
-        ca.st_acc_out = st_acc.p + (size_t)(acc_half ^ 1) * rows * chain_AR;
-        ca.fresh = t0 == 0 ? 1 : 0;
+        ca.st_acc = st_acc.p;
+        ca.acc_sel = acc_half | (t0 == 0 ? 2 : 0);
         if (!only_resample) acc_half ^= 1;
 #ifdef PV_DIAG
         // AUDIOMOD_PV_DEBUG_STALE_ACC=1 (diagnostic builds): recreate round 2's hazard on purpose -- one buffer for both
         // directions and a first launch that reads it -- to see what a run 0 that starts from the previous pass's final
         // accumulator image puts out (reset_state leaves the image alone under the same switch)
-        if (debug_stale_acc()) {
-            ca.st_acc_in = ca.st_acc_out = st_acc.p;
-            ca.fresh = 0;
-        }
+        if (debug_stale_acc()) ca.acc_sel = 4; // bit 2 (diagnostic builds): read AND write half 0, never fresh
 #endif
         ca.stream = stream.p;
         ca.resample = d.resample ? 1 : 0;
@@ -1023,6 +1021,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ra.out = out;
         ra.out_stride_row = out_stride_row;
         ra.k_base = k_base;
+        ra.fast = fast_arith && wave_fft() ? 1 : 0;
         if (d.resample && chain->res_stream && chain->ev_ring_free && !only_resample)
             HIPV(hipStreamWaitEvent(st, chain->ev_ring_free, 0));
         if (only_resample) {
@@ -1216,6 +1215,17 @@ const char *pv_strerror(int s) {
     }
 }
 
+static int g_arith = [] {
+    const char *e = getenv("AUDIOMOD_PV_EXACT");
+    return (e && atoi(e) != 0) ? PV_ARITH_EXACT : PV_ARITH_FAST;
+}();
+int pv_set_arithmetic(int arith) {
+    if (arith != PV_ARITH_FAST && arith != PV_ARITH_EXACT) return PV_ERR_INVALID_ARG;
+    g_arith = arith;
+    return PV_OK;
+}
+int pv_get_arithmetic(void) { return g_arith; }
+
 const char *pv_last_error(void) { return g_last_error.empty() ? plan_reason() : g_last_error.c_str(); }
 
 int pv_device_count(void) { return count_gfx950(); }
@@ -1300,6 +1310,7 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
         if (v >= 4 && v <= 1024) Tc = v;
     }
     b->core.pipelined_planes = Core::pipeline_wanted(*cfg);
+    b->core.fast_arith = g_arith == PV_ARITH_FAST;
     int st;
     {
         // the plan first: the overlap-add rings are sized from the advances it really contains

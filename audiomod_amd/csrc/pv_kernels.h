@@ -214,8 +214,8 @@ struct ChainArgs {
     int AR;     // accumulator ring (floats, multiple of 4, >= N + 4)
     int smask;  // stream ring size - 1 (power of two minus one)
     int waves;  // W: waves per workgroup (= slices of a row in flight)
-    int diag;   // measurement builds only (AUDIOMOD_PV_CHAIN_DIAG, results are wrong when set): bit 2 no waiting for
-                // the turn, bit 3 no synthesis
+    int diag;   // always 0 in the product library (a value the compiler cannot see through: pv_kernels.hip
+                // PV_CHAIN_DIAG); -DPV_DIAG builds set it from AUDIOMOD_PV_CHAIN_DIAG for elimination timings
     // A row's slices are processed by `runs` workgroups: run r walks slices[run_off[r] .. run_off[r + 1]), a list
     // that begins with the frames before its range whose tails reach into it (flag bit 1: rebuilt, not emitted)
     int runs;
@@ -223,14 +223,15 @@ struct ChainArgs {
     const ChainSlice *slices; // run lists, concatenated
     const float *wden;        // denominators, indexed wden_off + quad-relative sample
     const float *wden_hi;     // ... for channels > 0 (differs from wden only after a CONSTANT-mode overrun)
-    // Ring image carried between launches.  Run 0 of a row reads st_acc_in, the row's LAST run writes st_acc_out, and
-    // the two are different buffers (the engine swaps them per launch): with one buffer, the last run's workgroup
-    // could overwrite the image before a late-starting run 0 of the same launch had read it (nothing orders the
-    // workgroups of one launch).  fresh: the launch starts the stream (slice 0) -- the accumulator is all zeros by
-    // definition (channelinfo.cc:93-115) and nothing is read.
-    const float *st_acc_in;   // [rows][AR]
-    float *st_acc_out;        // [rows][AR]
-    int fresh;
+    // Ring images carried between launches: two halves of [rows][AR] each.  Run 0 of a row READS half (acc_sel & 1),
+    // the row's LAST run WRITES the other half, and the engine flips the bit per launch: with one buffer the last
+    // run's workgroup could overwrite the image before a late-starting run 0 of the same launch had read it (nothing
+    // orders the workgroups of one launch; seen in round 2 as a rare, deterministic wrong value).  acc_sel bit 1: the
+    // launch starts the stream (slice 0) -- the accumulator is all zeros by definition (channelinfo.cc:93-115) and
+    // nothing is read.  (One pointer and one int rather than two pointers and a flag: the fused kernel is short of
+    // scalar registers, and three more of them cost it 400 v_readlane reloads.)
+    float *st_acc;
+    int acc_sel;
     float *stream;            // [rows][smask + 1] normalised overlap-add stream (resampling configurations)
     int resample;
     // output (not resampling)
@@ -260,6 +261,7 @@ struct ResArgs {
     int lds_floats, tab_bytes;
     float *out;
     int64_t out_stride_row, k_base;
+    int fast; // arithmetic free within the 1e-4 RMS contract (pv_resample_fast_kernel) instead of the reference's order
 };
 void launch_resample(const ResArgs &a, hipStream_t st);
 size_t chain_lds_bytes(const ChainArgs &a, int nc_wave /* 0: frames from HBM */);

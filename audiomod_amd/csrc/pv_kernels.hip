@@ -971,6 +971,169 @@ __device__ __forceinline__ void seq_role(const SeqArgs &a, const int row, char *
     (void)c;
 }
 
+__host__ __device__ size_t seq_lds_bytes(const SeqArgs &a);
+// --------------------------------------------------------------------------------------------
+// The same walk with the step records prefetched kSeqDepth steps ahead through an LDS ring (round 3).  Elimination
+// builds (profiles/r02/seq_elim.txt) showed that a step of the loop above IS the latency of its one-step-ahead record
+// load (0.94 us with it, 0.54 without); register queues four to eight steps deep lost to the compiler's waits and
+// spills.  Here a wave fetches its own 64 records of step t + kSeqDepth - 1 with ONE global_load_lds_dwordx4 (LDS-DMA:
+// no destination registers, so nothing to spill and nothing the compiler waits for) into slot (t - 1) % kSeqDepth --
+// the slot step t - 1 has just finished with -- and reads step t's records from LDS.  The loads, the rotation store
+// and their waits are inline assembly so that the vmcnt counts below are exact; the compiler sees no vector memory
+// operation in the fast loop.  Arithmetic: the loop above, operation for operation.
+//
+// Waits.  VM operations retire in issue order (one counter on gfx9).  At the end of iteration t the records of step
+// t + 1 must have landed.  Issued behind that load by then: the loads of steps t + 2 .. t + kSeqDepth - 1 (those that
+// exist) and one store per iteration since it was issued, so
+//     steady state (the last kSeqDepth - 1 iterations all took the fast path):  vmcnt(2 kSeqDepth - 3)
+//     conservative (start of the launch, behind a general step):               vmcnt(kSeqDepth - 2), loads only
+//     tail (no more loads issued):                                             vmcnt(kSeqDepth - 1) resp. vmcnt(0)
+// a count that is too small only waits longer.  The wait sits in front of the step's barrier, the read behind it: the
+// step header (last record slot) is read by every wave, and data an LDS-DMA wrote is another wave's to read only
+// after that wave's wait and a barrier.
+// --------------------------------------------------------------------------------------------
+constexpr int kSeqDepthMax = 8;
+
+__device__ __forceinline__ void seq_glds16(const void *gsrc, uint32_t lds_dst) { // lds_dst: wave-uniform byte address
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+template <int N> __device__ __forceinline__ void seq_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N < 0 ? 0 : N) : "memory");
+}
+
+// (the step's own LDS reads -- header and record -- are issued one step ahead as well, at the top of the step before,
+// so that a step's dependent chain is what it was with the record in registers: rotation read, three wraps, rotation
+// write, barrier.  Hence the waits below are for step t + 2.)
+template <int D> __device__ __forceinline__ void seq_role_ring(const SeqArgs &a, const int row, char *smem_raw) {
+    static_assert(D >= 4 && D <= kSeqDepthMax, "ring depth");
+    float *srot0 = reinterpret_cast<float *>(smem_raw);          // [PKP]
+    float *srot1 = srot0 + a.PKP;                                // [PKP]
+    float *spo = srot1 + a.PKP;                                  // [hs] full prev_out (valid when kind == 1)
+    uint16_t *spk = reinterpret_cast<uint16_t *>(spo + a.hs);    // [PKP] peaks of the previous same-row step
+    const int nt = blockDim.x, tid = threadIdx.x, hs = a.hs;
+    PeakRec *ring = reinterpret_cast<PeakRec *>(smem_raw + ((seq_lds_bytes(a) + 15) & ~(size_t)15)); // [D][nt]
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)reinterpret_cast<char *>(ring);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int kind = a.st_kind[row];
+    float *rprev = srot0, *rcur = srot1;
+    if (kind == 2)
+        for (int i = tid; i < a.PKP; i += nt) rprev[i] = a.st_rot[(int64_t)row * a.PKP + i];
+    if (kind == 1)
+        for (int i = tid; i < hs; i += nt) spo[i] = a.st_po[(int64_t)row * hs + i];
+    __syncthreads(); // (the compiler's loads above are complete: it waited for their values)
+    const float hop_f = (float)a.hop;
+    const double Nd = (double)a.N;
+    auto plane_of = [&](int tl) { return (int64_t)row * a.TR + ring_slot(a.s0, tl, a.TR); };
+    const int rix = tid < a.PKP ? tid : a.PKP - 1; // (nt >= PKP: every peak has its own lane)
+    auto fetch = [&](int step) { // this wave's 64 records of `step` into the step's ring slot
+        const PeakRec *src = a.recs + plane_of(step) * a.PKP + rix;
+        const uint32_t dst = ring_lds + (uint32_t)(((step % D) * nt + wave * 64) * (int)sizeof(PeakRec));
+        seq_glds16(src, __builtin_amdgcn_readfirstlane(dst));
+    };
+    for (int sft = 0; sft < D - 1 && sft < a.Tn; ++sft) fetch(sft);
+    if (a.Tn >= D - 1) seq_wait_barrier<D - 3>(); // steps 0 and 1 have landed (D - 3 younger loads may be in flight)
+    else seq_wait_barrier<0>();
+    uint32_t h_next = ring[a.PKP - 1].p1r1;
+    PeakRec r_next = ring[tid];
+
+    int fast_run = 0; // consecutive iterations, ending with the current one, that issued exactly one (asm) store
+    for (int tl = 0; tl < a.Tn; ++tl) {
+        if (tl - 1 + D < a.Tn) fetch(tl - 1 + D); // into the slot step tl - 1 used: every wave is past that step's barrier
+        const uint32_t h0 = h_next;
+        const PeakRec r = r_next;
+        if (tl + 1 < a.Tn) { // the next step's header and record (landed: the wait at the end of step tl - 1)
+            const PeakRec *slot = ring + ((tl + 1) % D) * nt;
+            h_next = slot[a.PKP - 1].p1r1;
+            r_next = slot[tid];
+        }
+        const int mode = (int)(h0 & 3u);
+        const int64_t plane = plane_of(tl);
+        if (mode == kModeLock) {
+            // ---- phase-locked step: branch-free over the lanes (lanes beyond the peak count run on whatever their
+            // record slot holds and write slots nobody reads)
+            const uint32_t r1 = min(r.p1r1 >> 16, (uint32_t)(a.PKP - 1));
+            const uint32_t p1 = (r.p1r1 & 0xffffu) & (uint32_t)(hs - 1);
+            const float po_lock = (float)princarg_small((double)(r.a1 + rprev[r1]));
+            const float po_full = spo[p1];
+            const float po = kind == 2 ? po_lock : (kind == 1 ? po_full : 0.f);
+            const float tgt = (float)princarg_f(po + r.adv);
+            const float rt = (float)princarg_small((double)(tgt - r.a2));
+            rcur[rix] = rt;
+            {
+                float *dst = a.rot + plane * a.PKP + rix;
+                asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(rt) : "memory");
+            }
+            kind = 2;
+            float *tmp = rprev;
+            rprev = rcur;
+            rcur = tmp;
+            ++fast_run;
+        } else {
+            // ---- per-bin step (first slice, silence): prev_out materialised when the previous step was locked
+            fast_run = 0;
+            const int64_t t = a.t0 + tl;
+            const float *__restrict__ A = a.phase + plane * a.HP;
+            const int64_t splane = t > 0 ? (int64_t)row * a.TR + ring_prev(ring_slot(a.s0, tl, a.TR), a.TR) : -1;
+            const float *__restrict__ Ap = splane >= 0 ? a.phase + splane * a.HP : nullptr;
+            int nsame = 0;
+            if (kind == 2) {
+                nsame = a.npk[splane];
+                for (int i = tid; i < nsame; i += nt) spk[i] = a.peaks[splane * a.PKP + i];
+                __syncthreads();
+            }
+            const float pinc_f = (float)a.phase_inc[tl];
+            float *__restrict__ outp = a.outphase + plane * a.HP;
+            for (int i = tid; i < hs; i += nt) {
+                const float phi = A[i];
+                float outv;
+                if (mode == kModeInit) {
+                    outv = phi;
+                } else {
+                    float po;
+                    if (kind == 2) po = (float)princarg_small((double)(Ap[i] + rprev[region_of(spk, nsame, i)]));
+                    else if (kind == 1) po = spo[i];
+                    else po = 0.f;
+                    const float pp = Ap ? Ap[i] : 0.f;
+                    const float omega = (float)((a.two_pi_hop * (double)i) / Nd);
+                    const float d1 = phi - pp - omega;
+                    const float delta = (float)((double)omega + princarg_f(d1));
+                    const float advance = delta * pinc_f / hop_f;
+                    outv = (float)princarg_f(po + advance);
+                }
+                spo[i] = outv;
+                outp[i] = outv;
+            }
+            kind = 1;
+        }
+        // ---- the records of step tl + 2 have landed; then the step's barrier
+        if (tl + 2 >= a.Tn) {
+            seq_wait_barrier<0>();
+        } else if (fast_run >= D - 2) {
+            if (tl - 1 + D < a.Tn) seq_wait_barrier<2 * D - 5>();
+            else seq_wait_barrier<D - 2>();
+        } else {
+            if (tl - 1 + D < a.Tn) seq_wait_barrier<D - 3>();
+            else seq_wait_barrier<0>();
+        }
+    }
+    if (kind == 2)
+        for (int i = tid; i < a.PKP; i += nt) a.st_rot[(int64_t)row * a.PKP + i] = rprev[i];
+    if (kind == 1)
+        for (int i = tid; i < hs; i += nt) a.st_po[(int64_t)row * hs + i] = spo[i];
+    if (tid == 0) a.st_kind[row] = kind;
+}
+
+template <int D> __global__ __launch_bounds__(1024) void pv_seq_ring_kernel(const SeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
+    if (a.high_prio) __builtin_amdgcn_s_setprio(3);
+    seq_role_ring<D>(a, blockIdx.x, smem_raw);
+}
+
 template <int kK> __global__ __launch_bounds__(1024) void pv_seq_kernel(const SeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
@@ -986,7 +1149,7 @@ int seq_threads(int PKP) {
     if (nt < 64) nt = 64;
     return nt;
 }
-size_t seq_lds_bytes(const SeqArgs &a) { return sizeof(float) * ((size_t)2 * a.PKP + a.hs) + sizeof(uint16_t) * a.PKP; }
+__host__ __device__ size_t seq_lds_bytes(const SeqArgs &a) { return sizeof(float) * ((size_t)2 * a.PKP + a.hs) + sizeof(uint16_t) * a.PKP; }
 
 void launch_seq(const SeqArgs &a, hipStream_t st) {
     const size_t lds = seq_lds_bytes(a);
@@ -1001,6 +1164,27 @@ void launch_seq(const SeqArgs &a, hipStream_t st) {
         return;
     }
     const int nt = seq_threads(a.PKP);
+    static const bool no_ring = [] { // AUDIOMOD_PV_SEQ_RING=0: round 2's one-step-ahead register prefetch (for A/B runs)
+        const char *e = getenv("AUDIOMOD_PV_SEQ_RING");
+        return e && atoi(e) == 0;
+    }();
+    static const int depth = [] { // AUDIOMOD_PV_SEQ_DEPTH=4|8 (tuning knob)
+        const char *e = getenv("AUDIOMOD_PV_SEQ_DEPTH");
+        return e ? atoi(e) : 4;
+    }();
+    const int D = depth <= 4 ? 4 : 8;
+    const size_t ring_lds = ((lds + 15) & ~(size_t)15) + (size_t)D * nt * sizeof(PeakRec);
+    if (!no_ring && a.PKP <= nt && ring_lds <= 160 * 1024 - 512) {
+        static unsigned long long bigr4 = 0, bigr8 = 0;
+        if (D == 4) {
+            allow_big_lds_dev(pv_seq_ring_kernel<4>, bigr4);
+            hipLaunchKernelGGL(pv_seq_ring_kernel<4>, dim3(a.rows), dim3(nt), ring_lds, st, a);
+        } else {
+            allow_big_lds_dev(pv_seq_ring_kernel<8>, bigr8);
+            hipLaunchKernelGGL(pv_seq_ring_kernel<8>, dim3(a.rows), dim3(nt), ring_lds, st, a);
+        }
+        return;
+    }
     allow_big_lds_dev(pv_seq_kernel<1>, big1);
     hipLaunchKernelGGL(pv_seq_kernel<1>, dim3(a.rows), dim3(nt), lds, st, a);
 }
@@ -2202,13 +2386,13 @@ __device__ __forceinline__ float dpp_ror1(float v) { // lane i <- lane i - 1, la
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xf, 0xf, false));
 }
 
-// Measurement switches of the fused kernel (tools/chain_diag.sh: parts switched off, results meaningless) exist only in
-// builds made with -DPV_DIAG (tools/build_variant.sh); the product library has none of them.
-#ifdef PV_DIAG
+// ChainArgs::diag is ALWAYS ZERO in the product library: nothing reads AUDIOMOD_PV_CHAIN_DIAG there (pv_engine.cc sets
+// the field only under -DPV_DIAG, for tools/chain_diag.sh's elimination runs).  The tests on it stay in the code
+// because they are opaque to the compiler: round 3 compiled them out and the kernel ran 20 % SLOWER (0.73 vs 0.60 ms
+// per 128 K slices, same source otherwise, profiles/r03/fused_fence_ab.txt) -- without these three conditional
+// regions the scheduler moves work across the synthesis / turn / finalise boundaries and pays for it in scalar-register
+// reloads.  They are code-motion fences that happen to double as measurement switches in diagnostic builds.
 #define PV_CHAIN_DIAG(c, bit) (((c).diag & (bit)) != 0)
-#else
-#define PV_CHAIN_DIAG(c, bit) false
-#endif
 
 struct ChainLds {
     float *acc;   // [AR]
@@ -2229,8 +2413,8 @@ __host__ __device__ inline size_t chain_shared_bytes(const ChainArgs &c) {
 // by re-adding the frames before it, ChainSlice flag bit 1)
 __device__ __forceinline__ void chain_prologue(const ChainArgs &c, const ChainLds &l, int row, bool first_run = true) {
     const int nt = blockDim.x, tid = threadIdx.x;
-    const float4 *sa = reinterpret_cast<const float4 *>(c.st_acc_in + (int64_t)row * c.AR);
-    const bool carried = first_run && !c.fresh; // (a stream's first launch starts from the empty accumulator)
+    const float4 *sa = reinterpret_cast<const float4 *>(c.st_acc + ((int64_t)(c.acc_sel & 1) * c.rows + row) * c.AR);
+    const bool carried = first_run && !(c.acc_sel & 2); // (a stream's first launch starts from the empty accumulator)
     for (int i = tid; i < c.AR / 4; i += nt)
         reinterpret_cast<float4 *>(l.acc)[i] = carried ? sa[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid == 0) *l.turn = 0;
@@ -2240,7 +2424,12 @@ __device__ __forceinline__ void chain_epilogue(const ChainArgs &c, const ChainLd
     __syncthreads(); // every wave has passed its last turn
     if (!last_run) return; // only the run that ends the launch holds the row's true accumulator
     const int nt = blockDim.x, tid = threadIdx.x;
-    float4 *sa = reinterpret_cast<float4 *>(c.st_acc_out + (int64_t)row * c.AR);
+#if defined(PV_DIAG)
+    const int wr_half = (c.acc_sel & 4) ? 0 : ((c.acc_sel & 1) ^ 1); // (AUDIOMOD_PV_DEBUG_STALE_ACC: round 2's single buffer)
+#else
+    const int wr_half = (c.acc_sel & 1) ^ 1;
+#endif
+    float4 *sa = reinterpret_cast<float4 *>(c.st_acc + ((int64_t)wr_half * c.rows + row) * c.AR);
     for (int i = tid; i < c.AR / 4; i += nt) sa[i] = reinterpret_cast<const float4 *>(l.acc)[i];
 }
 
@@ -2766,7 +2955,101 @@ __global__ __launch_bounds__(kTileOut) void pv_resample_kernel(const ResArgs a) 
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// The same resampling with the arithmetic the 1e-4 RMS contract leaves free (ResArgs::fast; the batch engine's
+// default, audiomod_pv.h pv_set_arithmetic).  The output of the reference's interpolating resampler is
+//     sum_j x[j] * (c0 T0[j] + c1 T1[j] + c2 T2[j] + c3 T3[j])          (resample.c:494-543, regrouped)
+// and the bracket -- the cubic-interpolated filter tap -- depends on the output index only, not on the row: every
+// row of a batch follows one schedule.  So a thread interpolates each tap ONCE (one multiply + three fma) and applies
+// it to the same output of NR rows with one fma per row: (4 + NR) / NR fused operations per row and tap where the
+// reference's operation order needs four multiplies and four adds (~4.5x fewer vector instructions at NR = 8).  The
+// result differs from the reference's by rounding only (~1e-7 relative: one accumulator instead of four, fma).
+// --------------------------------------------------------------------------------------------
+constexpr int kResFastRows = 8;
+
+template <int kRes, int NR> // 1 = direct sinc table, 2 = cubic-interpolated table
+__global__ __launch_bounds__(kTileOut) void pv_resample_fast_kernel(const ResArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
+    float4 *tab4 = reinterpret_cast<float4 *>(smem_raw);
+    float *stab = reinterpret_cast<float *>(smem_raw);
+    float *xs = reinterpret_cast<float *>(smem_raw + a.tab_bytes); // [NR][lds_floats]
+    const int nt = blockDim.x, tid = threadIdx.x;
+    const ResTile tile = a.tiles[blockIdx.x];
+    const int row0 = blockIdx.y * NR, NF = a.filt_len;
+    const int nr = a.rows - row0 < NR ? a.rows - row0 : NR;
+    uint2 oe = make_uint2(0u, 0u);
+    if (tid < tile.kcnt) oe = a.otab[(int64_t)blockIdx.x * kTileOut + tid];
+    // the tile's stream samples of every row (a missing row re-reads the group's first: computed, never stored)
+    for (int i = tid; i < tile.n_cnt; i += nt) {
+        const int64_t n = tile.n_lo + i; // the stream is zero before its first sample (skip_zeros, :1225)
+        float xv[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float *__restrict__ st = a.stream + (int64_t)(r < nr ? row0 + r : row0) * ((int64_t)a.smask + 1);
+            xv[r] = n >= 0 ? st[(uint32_t)n & (uint32_t)a.smask] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) xs[r * a.lds_floats + i] = xv[r];
+    }
+    if (kRes == 2) {
+        const int cnt = a.oversample * (NF + 1);
+        for (int i = tid; i < cnt; i += nt) tab4[i] = a.tab4[i];
+    } else {
+        for (int i = tid; i < a.sinc_len; i += nt) stab[i] = a.sinc[i];
+    }
+    __syncthreads();
+    if (tid >= tile.kcnt) return;
+    float *__restrict__ out = a.out + (int64_t)row0 * a.out_stride_row + (tile.k0 - a.k_base) + tid;
+    const float *x = xs + (int)(oe.x & 0xffffu); // tap j = 0
+    float acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = 0.f;
+    if (kRes == 2) {
+        const float frac = __uint_as_float(oe.y);
+        // cubic_coef (resample.c:339-351)
+        const float c0 = -0.16667f * frac + 0.16667f * frac * frac * frac;
+        const float c1 = frac + 0.5f * frac * frac - 0.5f * frac * frac * frac;
+        const float c3 = -0.33333f * frac + 0.5f * frac * frac - 0.16667f * frac * frac * frac;
+        const float c2 = (float)(1. - c0 - c1 - c3);
+        const float4 *__restrict__ T = tab4 + (int)(oe.x >> 16) * (NF + 1);
+#pragma unroll 4
+        for (int j = 0; j < NF; ++j) { // NF is a multiple of 4 (resample.c:687)
+            const float4 c = T[j];
+            const float h = __builtin_fmaf(c3, c.w, __builtin_fmaf(c2, c.z, __builtin_fmaf(c1, c.y, c0 * c.x)));
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[r] = __builtin_fmaf(x[r * a.lds_floats + j], h, acc[r]);
+        }
+    } else {
+        const float *t = stab + (oe.x >> 16) * (uint32_t)NF;
+#pragma unroll 4
+        for (int j = 0; j < NF; ++j) {
+            const float h = t[j];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[r] = __builtin_fmaf(x[r * a.lds_floats + j], h, acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+        if (r < nr) out[(int64_t)r * a.out_stride_row] = acc[r];
+}
+
+static void launch_resample_fast(const ResArgs &a, hipStream_t st) {
+    constexpr int NR = kResFastRows;
+    const size_t lds = (size_t)a.tab_bytes + sizeof(float) * (size_t)a.lds_floats * NR;
+    const dim3 grid(a.ntiles, (a.rows + NR - 1) / NR);
+    static unsigned long long m1 = 0, m2 = 0;
+    if (a.interp) {
+        allow_big_lds_dev(pv_resample_fast_kernel<2, NR>, m2);
+        hipLaunchKernelGGL((pv_resample_fast_kernel<2, NR>), grid, dim3(kTileOut), lds, st, a);
+    } else {
+        allow_big_lds_dev(pv_resample_fast_kernel<1, NR>, m1);
+        hipLaunchKernelGGL((pv_resample_fast_kernel<1, NR>), grid, dim3(kTileOut), lds, st, a);
+    }
+}
+
 void launch_resample(const ResArgs &a, hipStream_t st) {
+    if (a.fast) return launch_resample_fast(a, st);
     if (a.ntiles <= 0) return;
     const size_t lds = (size_t)a.tab_bytes + sizeof(float) * (size_t)a.lds_floats * kResRows;
     const dim3 grid(a.ntiles, (a.rows + kResRows - 1) / kResRows);

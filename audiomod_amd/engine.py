@@ -116,8 +116,27 @@ def lib():
     L.pv_host_alloc.argtypes = [C.c_size_t]
     L.pv_host_alloc.restype = C.c_void_p
     L.pv_host_free.argtypes = [C.c_void_p]
+    L.pv_set_arithmetic.argtypes = [C.c_int]
+    L.pv_get_arithmetic.restype = C.c_int
     _lib = L
     return L
+
+
+ARITH_FAST, ARITH_EXACT = 0, 1
+
+
+def set_arithmetic(arith):
+    """Process-wide, read at engine creation (include/audiomod_pv.h pv_set_arithmetic): ARITH_FAST (default) lets the
+    many-stream batch path fuse / regroup the synthesis side's arithmetic within the 1e-4 RMS contract; ARITH_EXACT keeps
+    the reference's operation order everywhere.  Returns the previous setting."""
+    L = lib()
+    prev = L.pv_get_arithmetic()
+    _check(L.pv_set_arithmetic(int(arith)), "pv_set_arithmetic")
+    return prev
+
+
+def get_arithmetic():
+    return lib().pv_get_arithmetic()
 
 
 def _check(st, what):

@@ -77,6 +77,24 @@ typedef struct pv_info {
     int64_t bytes_per_slice; /* algorithmic HBM bytes per slice, SURVEY.md section 8(d): 4*(3N+7H+2s+h) */
 } pv_info;
 
+/* Arithmetic of the synthesis side (process-wide setting, read when an engine is created; default PV_ARITH_FAST,
+ * or PV_ARITH_EXACT when the environment has AUDIOMOD_PV_EXACT=1).
+ *   Everything up to and including the phase propagation -- window, forward FFT, magnitudes, atan2f, peak picking and
+ *   matching, the float / double phase chain -- always follows the reference's x86 build operation for operation
+ *   (separate multiplies and adds, its libm's atan2f): the propagation is discontinuous in those values, so nothing
+ *   short of the same bits is safe there.  Behind it the output is a continuous function of its inputs, and
+ *   BASELINE.json's contract is 1e-4 RMS:
+ *   PV_ARITH_EXACT  resynthesis, overlap-add, normalisation and resampling also in the reference's operation order
+ *                   (bit-identical to the reference except for the sine / cosine of the resynthesis; ROBOTIC mode
+ *                   bit-identical end to end);
+ *   PV_ARITH_FAST   the many-stream batch path (pv_batch_*, pv_hostio_* at 192 rows and up) may fuse multiply-adds,
+ *                   regroup sums and skip phase wraps there (measured: ~1e-8 RMS against the reference).  The
+ *                   single-stream engine (pv_create) and small batches compute as PV_ARITH_EXACT either way. */
+#define PV_ARITH_FAST 0
+#define PV_ARITH_EXACT 1
+int pv_set_arithmetic(int arith);
+int pv_get_arithmetic(void);
+
 const char *pv_strerror(int status);
 const char *pv_last_error(void);
 /* number of visible HIP devices that are gfx950; <= 0 means the library cannot run */

@@ -578,7 +578,10 @@ np.savez(sys.argv[1], *outs)
 """ % (ROOT,)
     def both_paths(d):
         files = []
-        for tag, env in (("fused", {"AUDIOMOD_PV_FUSED": "2"}), ("tiles", {"AUDIOMOD_PV_FUSED": "0"})):
+        # (AUDIOMOD_PV_EXACT=1: the batch engine's default arithmetic regroups the synthesis side's sums on the fused
+        # path -- this test is about the exact variant's order of additions)
+        for tag, env in (("fused", {"AUDIOMOD_PV_FUSED": "2", "AUDIOMOD_PV_EXACT": "1"}),
+                         ("tiles", {"AUDIOMOD_PV_FUSED": "0", "AUDIOMOD_PV_EXACT": "1"})):
             f = os.path.join(d, f"{tag}.npz")
             r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,
                                env=dict(os.environ, **env), timeout=900)
@@ -749,3 +752,40 @@ def test_device_atan2f_is_libms_bit_for_bit():
         wm = np.sqrt((x * x).astype(np.float32) + (y * y).astype(np.float32), dtype=np.float32)
     bad = np.nonzero(mg.view(np.uint32) != wm.view(np.uint32))[0]
     assert bad.size == 0, (bad.size, y[bad[:5]], x[bad[:5]], mg[bad[:5]], wm[bad[:5]])
+
+
+FAST_CASES = [dict(semitones=4.0), dict(semitones=-7.0, mode="formant_pitchshift"), dict(semitones=12.0),
+              dict(semitones=7.0, mode="gender_change"), dict(mode="time_stretch", time_ratio=1.5, fftsize=4096, flush=False)]
+
+
+@pytest.mark.parametrize("kw", FAST_CASES, ids=[str(i) for i in range(len(FAST_CASES))])
+def test_fast_arithmetic_of_the_batch_path_stays_within_the_contract(kw):
+    """PV_ARITH_FAST (the batch engine's default, include/audiomod_pv.h) lets the fused many-stream path -- 192 rows and
+    up -- fuse multiply-adds and regroup sums behind the phase propagation.  Both settings against the oracle on a
+    batch large enough to take that path (every stream its own signal): fast within the 1e-4 RMS contract -- and, as
+    measured, within 1e-6 -- exact as before; the two differ by rounding only."""
+    import torch
+    kw = dict(kw)
+    flush = kw.pop("flush", True)
+    S, F = 96, 16000
+    x = np.stack([signals.voice(F, 2, stream=s) for s in range(S)])
+    d_in = torch.from_numpy(x).cuda()
+    outs = {}
+    prev = E.get_arithmetic()
+    try:
+        for arith in (E.ARITH_FAST, E.ARITH_EXACT):
+            E.set_arithmetic(arith)
+            b = E.Batch(S, F, channels=2, flush=flush, **kw)
+            o = b.run(d_in)
+            torch.cuda.synchronize()
+            outs[arith] = o.cpu().numpy()
+            b.close()
+    finally:
+        E.set_arithmetic(prev)
+    for s in (0, 37, 95):
+        want, _, _ = O.run_offline(x[s], flush=flush, **kw)
+        assert outs[E.ARITH_EXACT][s].shape == want.shape
+        assert rms(outs[E.ARITH_EXACT][s], want) <= RMS_TOL
+        r = rms(outs[E.ARITH_FAST][s], want)
+        assert r <= 1e-6, r
+    assert rms(outs[E.ARITH_FAST], outs[E.ARITH_EXACT]) <= 1e-6
