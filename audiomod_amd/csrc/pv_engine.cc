@@ -337,6 +337,21 @@ struct Core {
         return !(sl && strcmp(sl, "single") == 0);               // the separate stages' device functions
     }
     bool wave_fft() const { return d.fft.nc == 1024 || d.fft.nc == 2048; }
+    // PV_ARITH_FAST and a free-form fused kernel exists for this configuration (pv_kernels.hip launch_synth_chain):
+    // the window-sum denominators are then uploaded as reciprocals
+    bool fast_chain() const {
+        if (!(fast_arith && use_chain && wave_fft())) return false;
+        SynthArgs sa{};
+        sa.tb.nc = d.fft.nc;
+        sa.do_freq_comp = d.do_freq_comp ? 1 : 0;
+        sa.voc_band_len = d.vocoder ? d.voc_band_len : -1;
+        sa.robotic = d.robotic ? 1 : 0;
+        sa.passthru = d.constant ? 1 : 0;
+        sa.whisper = d.whisper ? reinterpret_cast<const float *>(this) : nullptr; // (only tested against null)
+        const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder;
+        sa.coremode = bypass ? 0 : ((d.cfg.coremode == 1 || d.cfg.coremode == 2) ? d.cfg.coremode : 0);
+        return synth_chain_has_fast(sa);
+    }
 
     int init(const pv_config &cfg, int dev, int nstreams, int chunk_slices);
     int reset_state(hipStream_t st);
@@ -1001,6 +1016,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ca.frames = frames.p;
         ca.FR = FR;
         ca.t0 = t0;
+        ca.fast = fast_chain() ? 1 : 0;
         ResArgs ra{};
         ra.rows = rows;
         ra.ntiles = chain->res_ntiles;
@@ -1409,6 +1425,10 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
         // (one spare entry each: a slice that finalises or emits nothing still prefetches its first entry)
         while (wden.size() & 3) wden.push_back(1.f), wden_hi.push_back(1.f);
         for (int i = 0; i < 4; ++i) wden.push_back(1.f), wden_hi.push_back(1.f);
+        if (c.fast_chain()) { // the free-form kernel normalises by multiplying
+            for (float &v : wden) v = 1.0f / v;
+            for (float &v : wden_hi) v = 1.0f / v;
+        }
         if ((st = b->d_cs.upload(cs)) != PV_OK) return st;
         if ((st = b->d_run_off.upload(run_off)) != PV_OK) return st;
         if ((st = b->d_wden.upload(wden)) != PV_OK) return st;

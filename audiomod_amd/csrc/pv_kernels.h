@@ -241,7 +241,9 @@ struct ChainArgs {
     const float *frames; // [rows][FR][N]
     int FR;
     int64_t t0;
+    int fast; // host-side only: pick the free-form (PV_ARITH_FAST) kernel where one exists; wden then holds reciprocals
 };
+bool synth_chain_has_fast(const SynthArgs &s);
 
 // pv_resample_kernel: one workgroup = 256 outputs of two rows
 struct ResTile {

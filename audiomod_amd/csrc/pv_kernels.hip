@@ -1389,7 +1389,12 @@ __global__ __launch_bounds__(kFftThreads) void pv_synth_kernel(const SynthArgs a
 // kSink: 0 = the windowed frame goes to the HBM frame ring (a.frames); 1 = the un-windowed, un-shifted time-domain
 // frame stays in the wave's LDS region (element e at lds[W::pad(e)] = samples 2e, 2e + 1) for the fused
 // overlap-add that follows in the same kernel (pv_synth_chain_kernel)
-template <int NC, int kPlainCore = -1, int kSink = 0>
+// kFast: PV_ARITH_FAST (include/audiomod_pv.h) -- behind the phase propagation the output is continuous in everything
+// computed here, so the arithmetic is free within the 1e-4 RMS contract: the region rotation is added without the
+// wrap (sine and cosine do not care), sine / cosine come from the hardware's v_sin_f32 / v_cos_f32 (argument in turns),
+// complex products use fma, and the first FFT pass multiplies by literal twiddles (pv_wavefft.h).  ~30 % fewer vector
+// instructions per slice; measured against the oracle: see tests/test_gpu_parity.py (fast arithmetic) and bench.py.
+template <int NC, int kPlainCore = -1, int kSink = 0, bool kFast = false>
 __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int row, const int tl, cf *lds,
                                                 const int lane_in = -1) {
     // kPlainCore >= 0: the plain pitch shift / stretch in that core mode (no frequency compression, vocoder,
@@ -1524,6 +1529,7 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
             const int p0 = pre[wd];
             auto rotated = [&](float ph, int c) -> float {
                 const int reg = p0 + __popcll(word & ((2ull << (b0 + c)) - 1ull));
+                if (kFast) return ph + srot[reg]; // |.| <= 2 pi: the wrap only matters to a comparison, not to sin / cos
                 return (float)princarg_small((double)(ph + srot[reg]));
             };
             base[q] = make_float4(rotated(base[q].x, 0), rotated(base[q].y, 1), rotated(base[q].z, 2),
@@ -1550,7 +1556,15 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
     auto to_cartesian = [&](float mg, float p) -> cf {
         mg *= a.inv_n;
         float sn, cs;
-        sincosf(p, &sn, &cs);
+        if (kFast) { // phases unwrapped by freqCompSlice reach hundreds of radians: two-term reduction, then turns
+            const float n = __builtin_rintf(p * 0.15915494309189535f);
+            float r = __builtin_fmaf(n, -6.2831854820251465f, p);
+            r = __builtin_fmaf(n, 1.7484555e-07f, r);
+            const float rev = r * 0.15915494309189535f;
+            sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
+        } else {
+            sincosf(p, &sn, &cs);
+        }
         return cf{mg * cs, mg * sn};
     };
     auto spectrum_bin = [&](int k) -> cf {
@@ -1591,10 +1605,15 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
         auto to_cartesian_small = [&](float mg, float p) -> cf {
             mg *= a.inv_n;
             float sn, cs;
-            pv_sincos_small(p, sn, cs);
+            if (kFast) { // |p| is a few turns at most: v_sin_f32 / v_cos_f32 take turns, valid to +-256
+                const float rev = p * 0.15915494309189535f;
+                sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
+            } else {
+                pv_sincos_small(p, sn, cs);
+            }
             return cf{mg * cs, mg * sn};
         };
-        if (__builtin_amdgcn_ballot_w64(!(pmax <= PV_SINCOS_MAX_ARG)) == 0) {
+        if (kFast || __builtin_amdgcn_ballot_w64(!(pmax <= PV_SINCOS_MAX_ARG)) == 0) {
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 if (q < QB / 2) mreg[q + QB / 2] = *reinterpret_cast<const float4 *>(mag + 4 * (lane + 64 * (q + QB / 2)));
@@ -1645,7 +1664,7 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
     WfTw<W> T0, T1, T2;
     WfTwRaw<W, 1> raw1;
     if (kRoomy) {
-        wf_load_pass_tw<W, 0>(T0, lane, tw);
+        if (!(kFast && wf_pass_all_const<W, 0>())) wf_load_pass_tw<W, 0>(T0, lane, tw); // (fast: literal twiddles)
         wf_fetch_pass_tw<W, 1>(raw1, lane, twl);
     }
     cf pa[J], pb[J];
@@ -1668,7 +1687,8 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
             const cf fnkc = cf{pb[j].x, -pb[j].y};
             const cf fek = wf_add(fk, fnkc);
             const cf tq = wf_sub(fk, fnkc);
-            const cf fok = wf_cmul(tq, kRoomy ? sw[j] : stw[lane + 64 * j]);
+            const cf fok = kFast ? wf_cmul_fma(tq, kRoomy ? sw[j] : stw[lane + 64 * j])
+                                 : wf_cmul(tq, kRoomy ? sw[j] : stw[lane + 64 * j]);
             const cf u = wf_add(fek, fok);
             cf vv = wf_sub(fek, fok);
             vv.y = vv.y * -1.f;
@@ -1706,19 +1726,22 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
     if constexpr (kRoomy) {
         const int lp0 = wf_lane_part<W>(0, lane), lp1 = wf_lane_part<W>(1, lane), lp2 = wf_lane_part<W>(2, lane);
         wave_sync();
-        wf_apply_pass_stages<W, 0, true>(v, T0);
+        if (kFast) wf_apply_pass_stages_fast<W, 0, true>(v, T0);
+        else wf_apply_pass_stages<W, 0, true>(v, T0);
         wf_store<W, 0>(lds, v, lp0);
         wave_sync();
         wf_load<W, 1>(lds, v, lp1);
         wf_unpack_pass_tw<W, 1>(T1, raw1);
-        wf_apply_pass_stages<W, 1, true>(v, T1);
+        if (kFast) wf_apply_pass_stages_fast<W, 1, true>(v, T1);
+        else wf_apply_pass_stages<W, 1, true>(v, T1);
         WfTwRaw<W, 2> raw2;
         wf_fetch_pass_tw<W, 2>(raw2, lane, twl);
         wf_store<W, 1>(lds, v, lp1);
         wave_sync();
         wf_load<W, 2>(lds, v, lp2);
         wf_unpack_pass_tw<W, 2>(T2, raw2);
-        wf_apply_pass_stages<W, 2, true>(v, T2);
+        if (kFast) wf_apply_pass_stages_fast<W, 2, true>(v, T2);
+        else wf_apply_pass_stages<W, 2, true>(v, T2);
         if constexpr (kSink == 1) {
             wf_store<W, 2>(lds, v, lp2);
             wave_sync();
@@ -1743,20 +1766,37 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
         // no room to fetch a pass ahead, but the lane-major tables still turn each pass's twiddle gathers into a
         // few contiguous 16-byte loads
         wave_sync();
-        wf_fft_pass<W, 0, true>(v, lane, lds, tw);
+        if (kFast && wf_pass_all_const<W, 0>()) { // every twiddle of the pass is a literal: nothing to fetch
+            wf_apply_pass_stages_fast<W, 0, true>(v, T0);
+            wf_store<W, 0>(lds, v, wf_lane_part<W>(0, lane));
+        } else {
+            wf_fft_pass<W, 0, true>(v, lane, lds, tw);
+        }
         wave_sync();
         {
             WfTwRaw<W, 1> r1;
             wf_fetch_pass_tw<W, 1>(r1, lane, twl);
             wf_unpack_pass_tw<W, 1>(T1, r1);
-            wf_fft_pass_tw<W, 1, true>(v, lane, lds, T1);
+            if (kFast) {
+                wf_load<W, 1>(lds, v, wf_lane_part<W>(1, lane));
+                wf_apply_pass_stages_fast<W, 1, true>(v, T1);
+                wf_store<W, 1>(lds, v, wf_lane_part<W>(1, lane));
+            } else {
+                wf_fft_pass_tw<W, 1, true>(v, lane, lds, T1);
+            }
         }
         wave_sync();
         {
             WfTwRaw<W, 2> r2;
             wf_fetch_pass_tw<W, 2>(r2, lane, twl);
             wf_unpack_pass_tw<W, 2>(T2, r2);
-            wf_fft_pass_tw<W, 2, true>(v, lane, lds, T2);
+            if (kFast) {
+                wf_load<W, 2>(lds, v, wf_lane_part<W>(2, lane));
+                wf_apply_pass_stages_fast<W, 2, true>(v, T2);
+                wf_store<W, 2>(lds, v, wf_lane_part<W>(2, lane));
+            } else {
+                wf_fft_pass_tw<W, 2, true>(v, lane, lds, T2);
+            }
         }
         if constexpr (kSink == 1) {
             wave_sync();
@@ -2572,7 +2612,8 @@ __device__ __forceinline__ void chain_finish_slice(const ChainArgs &c_in, const 
 // lane's registers and are normalised and appended to the stream after the turn has been passed on.  The second
 // counter publishes, in slice order, that a slice's stream samples are written (the next slice's wave resamples the
 // outputs this one deferred).  wden is laid out by ring quads: entry 0 belongs to sample P_t - r.
-template <int R_, int NP, int kRes>
+// (kFast: the denominators arrive as reciprocals -- the host inverts them, pv_engine.cc -- and normalising is a multiply)
+template <int R_, int NP, int kRes, bool kFast = false>
 __device__ __forceinline__ void chain_slice_tail(const ChainArgs &c_in, const ChainLds &l, const ChainSlice &sl,
                                                  const float4 (&A)[NP], const bool skip, const int row, const int tl,
                                                  const int lane) {
@@ -2702,10 +2743,10 @@ __device__ __forceinline__ void chain_slice_tail(const ChainArgs &c_in, const Ch
                                    : *reinterpret_cast<const float4 *>(wden + 4 * (u < fin_quads ? u : 0));
             const int s0 = 4 * u - R_;
             if (j < NP || tail_lane) {
-                emit(s0, V[j].x / d.x);
-                emit(s0 + 1, V[j].y / d.y);
-                emit(s0 + 2, V[j].z / d.z);
-                emit(s0 + 3, V[j].w / d.w);
+                emit(s0, kFast ? V[j].x * d.x : V[j].x / d.x);
+                emit(s0 + 1, kFast ? V[j].y * d.y : V[j].y / d.y);
+                emit(s0 + 2, kFast ? V[j].z * d.z : V[j].z / d.z);
+                emit(s0 + 3, kFast ? V[j].w * d.w : V[j].w / d.w);
             }
         }
     }
@@ -2713,7 +2754,7 @@ __device__ __forceinline__ void chain_slice_tail(const ChainArgs &c_in, const Ch
 
 // (the all-modes variant -- frequency compression, vocoder, ... -- needs ~150 VGPRs where the plain ones fit 128:
 // compiled for twelve waves per workgroup, three per SIMD, instead of spilling)
-template <int NC, int kPlainCore, int kRes>
+template <int NC, int kPlainCore, int kRes, bool kFast = false>
 __global__ __launch_bounds__(NC == 1024 ? ((kPlainCore < 0 || kPlainCore == 3) ? 768 : 1024) : 512) void pv_synth_chain_kernel(
     const SynthArgs s, const ChainArgs c) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -2741,7 +2782,7 @@ __global__ __launch_bounds__(NC == 1024 ? ((kPlainCore < 0 || kPlainCore == 3) ?
         const bool skip = (sl.flags & 1) && upper; // wave-uniform
         float4 A[NP];
         if (!skip) {
-            if (!PV_CHAIN_DIAG(c, 8)) synth_wave_role<NC, kPlainCore, 1>(s, row, tl, wlds, lane);
+            if (!PV_CHAIN_DIAG(c, 8)) synth_wave_role<NC, kPlainCore, 1, kFast>(s, row, tl, wlds, lane);
             // ifftshift + synthesis window (phasevocoderimpl.h:183-198): four consecutive samples per lane and piece
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
@@ -2753,10 +2794,10 @@ __global__ __launch_bounds__(NC == 1024 ? ((kPlainCore < 0 || kPlainCore == 3) ?
             }
         }
         const int r = sl.acc_pos & 3; // wave-uniform
-        if (r == 0) chain_slice_tail<0, NP, kRes>(c, l, sl, A, skip, row, i, lane);
-        else if (r == 1) chain_slice_tail<1, NP, kRes>(c, l, sl, A, skip, row, i, lane);
-        else if (r == 2) chain_slice_tail<2, NP, kRes>(c, l, sl, A, skip, row, i, lane);
-        else chain_slice_tail<3, NP, kRes>(c, l, sl, A, skip, row, i, lane);
+        if (r == 0) chain_slice_tail<0, NP, kRes, kFast>(c, l, sl, A, skip, row, i, lane);
+        else if (r == 1) chain_slice_tail<1, NP, kRes, kFast>(c, l, sl, A, skip, row, i, lane);
+        else if (r == 2) chain_slice_tail<2, NP, kRes, kFast>(c, l, sl, A, skip, row, i, lane);
+        else chain_slice_tail<3, NP, kRes, kFast>(c, l, sl, A, skip, row, i, lane);
     }
     chain_epilogue(c, l, row, run == (int)gridDim.y - 1);
 }
@@ -2815,7 +2856,19 @@ size_t chain_lds_bytes(const ChainArgs &a, int nc_wave) {
 template <int NC, int kPlainCore> static void launch_synth_chain_res(const SynthArgs &s, const ChainArgs &c, hipStream_t st) {
     const size_t lds = chain_lds_bytes(c, NC);
     const dim3 grid(c.rows, c.runs), block(64 * c.waves);
-    static unsigned long long m0 = 0, m1 = 0;
+    static unsigned long long m0 = 0, m1 = 0, f0 = 0, f1 = 0;
+    if constexpr (kPlainCore >= 0) { // the specialisations have a free-form (PV_ARITH_FAST) twin
+        if (c.fast) {
+            if (!c.resample) {
+                allow_big_lds_dev(pv_synth_chain_kernel<NC, kPlainCore, 0, true>, f0);
+                hipLaunchKernelGGL((pv_synth_chain_kernel<NC, kPlainCore, 0, true>), grid, block, lds, st, s, c);
+            } else {
+                allow_big_lds_dev(pv_synth_chain_kernel<NC, kPlainCore, 1, true>, f1);
+                hipLaunchKernelGGL((pv_synth_chain_kernel<NC, kPlainCore, 1, true>), grid, block, lds, st, s, c);
+            }
+            return;
+        }
+    }
     if (!c.resample) {
         allow_big_lds_dev(pv_synth_chain_kernel<NC, kPlainCore, 0>, m0);
         hipLaunchKernelGGL((pv_synth_chain_kernel<NC, kPlainCore, 0>), grid, block, lds, st, s, c);
@@ -2823,6 +2876,15 @@ template <int NC, int kPlainCore> static void launch_synth_chain_res(const Synth
         allow_big_lds_dev(pv_synth_chain_kernel<NC, kPlainCore, 1>, m1);
         hipLaunchKernelGGL((pv_synth_chain_kernel<NC, kPlainCore, 1>), grid, block, lds, st, s, c);
     }
+}
+// does launch_synth_chain pick a free-form kernel for this configuration?  (the engine then uploads the window-sum
+// denominators as reciprocals)
+bool synth_chain_has_fast(const SynthArgs &s) {
+    const bool plain = !s.do_freq_comp && s.voc_band_len < 0 && !s.robotic && !s.passthru && !s.whisper &&
+                       !synth_generic_only() && s.coremode >= 0 && s.coremode <= 2;
+    const bool fc_locked = s.do_freq_comp && s.voc_band_len < 0 && !s.robotic && !s.passthru && !s.whisper &&
+                           !synth_generic_only() && s.coremode == 1;
+    return (s.tb.nc == 1024 && (plain || fc_locked)) || (s.tb.nc == 2048 && plain);
 }
 
 void launch_synth_chain(const SynthArgs &s, const ChainArgs &c, hipStream_t st) {

@@ -317,6 +317,131 @@ template <class W, int P, bool INV> PV_HD void wf_apply_pass_stages(cf (&v)[W::R
     if constexpr (F + 2 < W::NSTAGE && W::st_pass[F + 2] == P) wf_stage_apply<W, F + 2, INV>(v, T.t[2]);
 }
 
+// ---- free-form arithmetic (PV_ARITH_FAST: synthesis side only, include/audiomod_pv.h) -----------------------------
+// Same transform, same stage structure and data layout, but the operation order is no longer kissfft's: complex
+// products are two multiplies + two fma, and a stage whose twiddle index k lives entirely in REGISTER bits of its pass
+// (pass 0: k is a compile-time constant per butterfly) multiplies by literals -- nothing for k = 0, a swap for quarter
+// turns, two adds + two multiplies for eighth turns -- instead of by twiddles fetched per lane.  For 1024 points that
+// turns pass 0 into a 16-point transform with constant factors (24 fewer registers, 12 fewer loads, ~110 fewer
+// instructions per lane); results differ from the exact variant by rounding only.
+PV_HD cf wf_cmul_fma(cf a, cf b) {
+    cf m;
+    m.x = __builtin_fmaf(a.x, b.x, -(a.y * b.y));
+    m.y = __builtin_fmaf(a.x, b.y, a.y * b.x);
+    return m;
+}
+// cos / sin of 2 pi j / 32 (float of the double value, like kissfft's table entries)
+constexpr float kWfCos32[32] = {1.0f, 0.9807852506637573f, 0.9238795042037964f, 0.8314695954322815f, 0.7071067690849304f, 0.5555702447891235f, 0.3826834261417389f, 0.19509032368659973f, 0.0f, -0.19509032368659973f, -0.3826834261417389f, -0.5555702447891235f, -0.7071067690849304f, -0.8314695954322815f, -0.9238795042037964f, -0.9807852506637573f, -1.0f, -0.9807852506637573f, -0.9238795042037964f, -0.8314695954322815f, -0.7071067690849304f, -0.5555702447891235f, -0.3826834261417389f, -0.19509032368659973f, 0.0f, 0.19509032368659973f, 0.3826834261417389f, 0.5555702447891235f, 0.7071067690849304f, 0.8314695954322815f, 0.9238795042037964f, 0.9807852506637573f};
+constexpr float kWfSin32[32] = {0.0f, 0.19509032368659973f, 0.3826834261417389f, 0.5555702447891235f, 0.7071067690849304f, 0.8314695954322815f, 0.9238795042037964f, 0.9807852506637573f, 1.0f, 0.9807852506637573f, 0.9238795042037964f, 0.8314695954322815f, 0.7071067690849304f, 0.5555702447891235f, 0.3826834261417389f, 0.19509032368659973f, 0.0f, -0.19509032368659973f, -0.3826834261417389f, -0.5555702447891235f, -0.7071067690849304f, -0.8314695954322815f, -0.9238795042037964f, -0.9807852506637573f, -1.0f, -0.9807852506637573f, -0.9238795042037964f, -0.8314695954322815f, -0.7071067690849304f, -0.5555702447891235f, -0.3826834261417389f, -0.19509032368659973f};
+// a * exp(-+ 2 pi i J / 32)  (forward: minus; INV: plus)
+template <int J, bool INV> PV_HD cf wf_cmul_w32(cf a) {
+    constexpr int j = J & 31;
+    if constexpr (j == 0) {
+        return a;
+    } else if constexpr (j == 16) {
+        return cf{-a.x, -a.y};
+    } else if constexpr (j == 8) { // times (0, +-1)
+        return INV ? cf{-a.y, a.x} : cf{a.y, -a.x};
+    } else if constexpr (j == 24) {
+        return INV ? cf{a.y, -a.x} : cf{-a.y, a.x};
+    } else {
+        constexpr float c = kWfCos32[j];
+        constexpr float sI = INV ? kWfSin32[j] : -kWfSin32[j];
+        if constexpr ((j & 3) == 0) { // eighth turns: |c| == |s|
+            constexpr float h = 0.7071067690849304f;
+            constexpr float sc = c > 0.f ? 1.f : -1.f, ss = sI > 0.f ? 1.f : -1.f;
+            return cf{(sc * a.x - ss * a.y) * h, (ss * a.x + sc * a.y) * h};
+        } else {
+            return cf{__builtin_fmaf(a.x, c, -(a.y * sI)), __builtin_fmaf(a.x, sI, a.y * c)};
+        }
+    }
+}
+// radix-4 / radix-2 butterflies on already-multiplied inputs
+template <bool INV> PV_HD void wf_bfly4_core(cf &f0, cf &f1, cf &f2, cf &f3, const cf s0, const cf s1, const cf s2) {
+    const cf s5 = wf_sub(f0, s1);
+    const cf g0 = wf_add(f0, s1);
+    const cf s3 = wf_add(s0, s2);
+    const cf s4 = wf_sub(s0, s2);
+    f2 = wf_sub(g0, s3);
+    f0 = wf_add(g0, s3);
+    if (INV) {
+        f1 = cf{s5.x - s4.y, s5.y + s4.x};
+        f3 = cf{s5.x + s4.y, s5.y - s4.x};
+    } else {
+        f1 = cf{s5.x + s4.y, s5.y - s4.x};
+        f3 = cf{s5.x - s4.y, s5.y + s4.x};
+    }
+}
+// does stage S's twiddle index depend on register bits only?
+template <class W, int S> constexpr bool wf_stage_k_in_regs() {
+    const int pass = W::st_pass[S], eb = W::st_bit[S];
+    for (int b = 0; b < eb; ++b)
+        if (wf_find_regbit<W>(pass, b) < 0) return false;
+    return (1 << eb) * W::st_radix[S] <= 32;
+}
+template <class W, int S, bool INV, int RR> PV_HD void wf_stage_const_one(cf (&v)[W::R]) {
+    constexpr int pass = W::st_pass[S], eb = W::st_bit[S], radix = W::st_radix[S], m = 1 << eb;
+    constexpr int p = wf_find_regbit<W>(pass, eb);
+    if constexpr (((RR >> p) & (radix - 1)) == 0) {
+        constexpr int k = wf_reg_part<W>(pass, RR) & (m - 1);
+        constexpr int u = 32 / (m * radix); // twiddle q of this butterfly = W32^(k q u)
+        if constexpr (radix == 4) {
+            const cf s0 = wf_cmul_w32<k * u, INV>(v[RR + (1 << p)]);
+            const cf s1 = wf_cmul_w32<2 * k * u, INV>(v[RR + (2 << p)]);
+            const cf s2 = wf_cmul_w32<3 * k * u, INV>(v[RR + (3 << p)]);
+            wf_bfly4_core<INV>(v[RR], v[RR + (1 << p)], v[RR + (2 << p)], v[RR + (3 << p)], s0, s1, s2);
+        } else {
+            const cf t = wf_cmul_w32<k * u, INV>(v[RR + (1 << p)]);
+            v[RR + (1 << p)] = wf_sub(v[RR], t);
+            v[RR] = wf_add(v[RR], t);
+        }
+    }
+}
+template <class W, int S, bool INV, int... I>
+PV_HD void wf_stage_const_seq(cf (&v)[W::R], std::integer_sequence<int, I...>) {
+    (wf_stage_const_one<W, S, INV, I>(v), ...);
+}
+// stage S with free-form arithmetic: literal twiddles where k is in registers, fetched ones (t) with fma otherwise
+template <class W, int S, bool INV> PV_HD void wf_stage_apply_fast(cf (&v)[W::R], const cf (&t)[W::R]) {
+    if constexpr (wf_stage_k_in_regs<W, S>()) {
+        wf_stage_const_seq<W, S, INV>(v, std::make_integer_sequence<int, W::R>{});
+    } else {
+        constexpr int pass = W::st_pass[S], eb = W::st_bit[S], radix = W::st_radix[S];
+        constexpr int p = wf_find_regbit<W>(pass, eb);
+#pragma unroll
+        for (int r = 0; r < W::R; ++r) {
+            if ((r >> p) & (radix - 1)) continue;
+            if (radix == 4) {
+                const cf s0 = wf_cmul_fma(v[r + (1 << p)], t[r + (1 << p)]);
+                const cf s1 = wf_cmul_fma(v[r + (2 << p)], t[r + (2 << p)]);
+                const cf s2 = wf_cmul_fma(v[r + (3 << p)], t[r + (3 << p)]);
+                wf_bfly4_core<INV>(v[r], v[r + (1 << p)], v[r + (2 << p)], v[r + (3 << p)], s0, s1, s2);
+            } else {
+                const cf u = wf_cmul_fma(v[r + (1 << p)], t[r + (1 << p)]);
+                v[r + (1 << p)] = wf_sub(v[r], u);
+                v[r] = wf_add(v[r], u);
+            }
+        }
+    }
+}
+template <class W, int P, bool INV> PV_HD void wf_apply_pass_stages_fast(cf (&v)[W::R], const WfTw<W> &T) {
+    constexpr int F = wf_first_stage<W, P>();
+    if constexpr (F + 0 < W::NSTAGE && W::st_pass[F + 0] == P) wf_stage_apply_fast<W, F + 0, INV>(v, T.t[0]);
+    if constexpr (F + 1 < W::NSTAGE && W::st_pass[F + 1] == P) wf_stage_apply_fast<W, F + 1, INV>(v, T.t[1]);
+    if constexpr (F + 2 < W::NSTAGE && W::st_pass[F + 2] == P) wf_stage_apply_fast<W, F + 2, INV>(v, T.t[2]);
+}
+// true when no stage of pass P needs fetched twiddles in the fast variant
+template <class W, int P> constexpr bool wf_pass_all_const() {
+    for (int s = 0; s < W::NSTAGE; ++s)
+        if (W::st_pass[s] == P) {
+            const int eb = W::st_bit[s];
+            for (int b = 0; b < eb; ++b)
+                if (wf_find_regbit<W>(P, b) < 0) return false;
+            if ((1 << eb) * W::st_radix[s] > 32) return false;
+        }
+    return true;
+}
+
 template <class W, int P> PV_HD void wf_store(cf *lds, const cf (&v)[W::R], int lp) {
 #pragma unroll
     for (int r = 0; r < W::R; ++r) lds[W::pad(lp | wf_reg_part<W>(P, r))] = v[r];
