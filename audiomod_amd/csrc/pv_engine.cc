@@ -306,6 +306,7 @@ struct Core {
     static constexpr int kChainMinRows = 192;
     bool fast_arith = false;  // set before init() by the batch engine (audiomod_pv.h PV_ARITH_FAST); only the fused
                               // wave-FFT path has the fast kernels, everything else computes exactly either way
+    bool ahead = false;       // three-stage order with the analysis one chunk further ahead (pv_batch_run): planes hold three chunks
     bool three_stage = false; // pipelined batch path: resampling of chunk i-2 between the front of i and the fused kernel of i-1
     int chain_AR = 0, chain_smask = 0, chain_waves = 0;
     int chain_max_adv = 0; // set before init(): the largest overlap-add advance the planner can emit
@@ -497,7 +498,15 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     Tc = chunk_slices;
     // slice-indexed planes keep the last slice of the previous launch (pv_kernels.h); the pipelined batch path
     // has two chunks in flight (the front of chunk i+1 runs before the back of chunk i)
-    TR = (nstreams > 0 && pipelined_planes) ? 2 * Tc + 1 : Tc + 1;
+    {
+        // Round 3: with the free-form resampling kernel the rotation chain of chunk i (0.3-0.4 ms beside it) outlasts
+        // the resampling of chunk i-2 (0.28 ms) and delays the fused kernel, whose workgroups need whole CUs.  The
+        // analysis of chunk i+1 therefore moves in between -- M(i) -> chain(i) | R(i-2), A(i+1), F(i-1) -- which needs
+        // the planes of three chunks.  AUDIOMOD_PV_AHEAD=0: round 2's order.
+        const char *ea = getenv("AUDIOMOD_PV_AHEAD"), *er = getenv("AUDIOMOD_PV_RES_STREAM");
+        ahead = use_chain && three_stage && wave_fft() && !(ea && atoi(ea) == 0) && !(er && atoi(er) != 0);
+    }
+    TR = (nstreams > 0 && pipelined_planes) ? (ahead ? 3 : 2) * Tc + 1 : Tc + 1;
     FR = next_pow2_i(Tc + lookback + 1);
 
     // tables
@@ -782,10 +791,13 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     // overlap-add kernel, 4 = the resampling kernel), for the three-stage order of pv_batch_run
     // part 5: only the rotation chain's hand-over to the second stream (for the order in which the chain starts behind
     // the previous chunk's fused kernel rather than right behind its own match kernel: ChainLaunch::late_chain)
+    // part 6 / 7: the front of a chunk in two pieces (6 = the analysis kernel only, 7 = match kernel + the rotation
+    // chain's hand-over), for the order in which the analysis runs one chunk further ahead (pv_batch_run, ahead order)
     const bool only_resample = part == 4, no_resample = part == 3, only_chain = part == 5;
+    const bool only_analysis = part == 6, no_analysis = part == 7;
     const bool defer_chain = part == 1 && chain && chain->late_chain;
     if (part == 3 || part == 4) part = 2;
-    if (part == 5) part = 1;
+    if (part == 5 || part == 6 || part == 7) part = 1;
     const bool front = part != 2, back = part != 1;
     StreamArgs fused{};
     const bool bypass = d.robotic || d.whisper || d.constant || d.vocoder;
@@ -828,10 +840,11 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     aa.phase = phase.p;
     aa.peaks = peaks.p;
     aa.npk = npk.p;
-    if (front && !only_chain) rec(2 * PV_K_ANALYZE);
+    const bool do_analysis = front && !only_chain && !no_analysis;
+    if (do_analysis) rec(2 * PV_K_ANALYZE);
     if (single_launch) fused.aa = aa;
-    else if (front && !only_chain) launch_analyze(aa, st); HIPV(hipGetLastError());
-    if (front && !only_chain && d.vocoder && carrier) {
+    else if (do_analysis) launch_analyze(aa, st); HIPV(hipGetLastError());
+    if (do_analysis && d.vocoder && carrier) {
         // the carrier is one more (data-independent) row: same analysis, its own planes
         AnalyzeArgs ca = aa;
         ca.ia = *carrier;
@@ -841,7 +854,8 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ca.phase = cphase.p;
         launch_analyze(ca, st); HIPV(hipGetLastError());
     }
-    if (front && !only_chain) rec(2 * PV_K_ANALYZE + 1);
+    if (do_analysis) rec(2 * PV_K_ANALYZE + 1);
+    if (only_analysis) return;
 
     if (cm == 1) {
         MatchArgs ma{};
@@ -1534,18 +1548,25 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
     // (analysis, match), then the back of chunk i-1 (synthesis, overlap-add); the second stream walks chunk i's
     // rotation chain meanwhile, and has until the back of chunk i -- one more front later -- to finish.
     const bool piped = b->chain_stream != nullptr;
-    auto events_for = [&](size_t ci) -> hipEvent_t * {
-        if (!(b->timing > 0 && (int)(ci % (size_t)b->timing) == (b->timing / 2) % b->timing)) return nullptr;
+    // (indices first, pointers after the pool has stopped growing: a pointer into ev_pool taken before a later
+    // push_back would dangle)
+    std::vector<long> ev_index(b->chunks.size(), -1);
+    for (size_t ci = 0; ci < b->chunks.size(); ++ci) {
+        if (!(b->timing > 0 && (int)(ci % (size_t)b->timing) == (b->timing / 2) % b->timing)) continue;
         const size_t need = b->ev_used + kEvPerChunk;
-        while (b->ev_pool.size() < need) {
+        bool ok = true;
+        while (ok && b->ev_pool.size() < need) {
             hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) return nullptr;
-            b->ev_pool.push_back(e);
+            if (hipEventCreate(&e) != hipSuccess) ok = false;
+            else b->ev_pool.push_back(e);
         }
-        hipEvent_t *ev = &b->ev_pool[b->ev_used];
+        if (!ok) break;
+        ev_index[ci] = (long)b->ev_used;
         b->ev_used = need;
         b->ev_chunk.push_back((int)ci);
-        return ev;
+    }
+    auto events_for = [&](size_t ci) -> hipEvent_t * {
+        return ev_index[ci] >= 0 ? &b->ev_pool[(size_t)ev_index[ci]] : nullptr;
     };
     static const bool late_env = [] {
         const char *e = getenv("AUDIOMOD_PV_LATE_CHAIN");
@@ -1587,6 +1608,19 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
         // kernel, which fills the CUs' LDS, starts.
         const bool three = c.use_chain && c.d.resample && c.wave_fft() && b->res_stream == nullptr && c.three_stage;
         std::vector<hipEvent_t *> evs(nchunks, nullptr);
+        const bool ahead = three && c.ahead && !late;
+        if (ahead) {
+            for (size_t ci = 0; ci < nchunks; ++ci) evs[ci] = events_for(ci);
+            if (nchunks > 0) launch(0, evs[0], 6); // A(0)
+            for (size_t ci = 0; ci < nchunks; ++ci) {
+                launch(ci, evs[ci], 7);                                  // M(ci), chain(ci) handed to its stream
+                if (ci > 1) launch(ci - 2, evs[ci - 2], 4);              // R(ci-2)   beside the chain
+                if (ci + 1 < nchunks) launch(ci + 1, evs[ci + 1], 6);    // A(ci+1)   beside what is left of it
+                if (ci > 0) launch(ci - 1, evs[ci - 1], 3);              // F(ci-1)
+            }
+            if (nchunks > 1) launch(nchunks - 2, evs[nchunks - 2], 4);
+            if (nchunks > 0) launch(nchunks - 1, evs[nchunks - 1], 3), launch(nchunks - 1, evs[nchunks - 1], 4);
+        } else {
         for (size_t ci = 0; ci < nchunks; ++ci) {
             evs[ci] = events_for(ci);
             launch(ci, evs[ci], 1);
@@ -1603,6 +1637,7 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
             if (nchunks > 0) launch(nchunks - 1, evs[nchunks - 1], 3), launch(nchunks - 1, evs[nchunks - 1], 4);
         } else if (nchunks > 0) {
             launch(nchunks - 1, evs[nchunks - 1], 2);
+        }
         }
     } else {
         for (size_t ci = 0; ci < nchunks; ++ci) launch(ci, events_for(ci), 0);

@@ -25,7 +25,9 @@ def canonical(k):
         return "pv_ola_kernel"
     if k.startswith("pv_synth_chain_kernel"):  # fused synthesis + overlap-add
         return "pv_synth_ola_kernel"
-    if k.startswith("pv_resample_kernel") or k.startswith("pv_frames_chain_kernel"):
+    if k.startswith("pv_seq_ring_kernel") or k.startswith("pv_seq_kernel"):
+        return "pv_seq_kernel"
+    if k.startswith("pv_resample_kernel") or k.startswith("pv_resample_fast_kernel") or k.startswith("pv_frames_chain_kernel"):
         return "pv_ola_kernel"  # the fused path's second kernel, reported under the overlap-add stage's name
     return k
 
@@ -48,7 +50,11 @@ def main():
         f_kib, w_kib = med(c["FETCH_SIZE"]), med(c["WRITE_SIZE"])
         res[k] = int((2.0 * f_kib + w_kib) * 1024)
         detail[k] = {"FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib, "launches": len(c["FETCH_SIZE"])}
-    json.dump({"note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, median launch; "
+    sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    import bench
+    import os
+    arith = "exact" if os.environ.get("AUDIOMOD_PV_EXACT", "0") not in ("", "0") else "fast"
+    json.dump({"source_sha16": bench.kernel_source_hash(), "arithmetic": arith, "note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, median launch; "
                        "bench workload geometry (128 stereo streams; since round 2's last change 512-slice chunks = 131072 slices "
                        "per launch, 65536 before -- compare with the bench line's roofline.slices_per_launch)",
                "bytes_per_launch": res, "counters": detail}, open(out, "w"), indent=1)
