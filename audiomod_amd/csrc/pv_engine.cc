@@ -1051,7 +1051,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ra.out = out;
         ra.out_stride_row = out_stride_row;
         ra.k_base = k_base;
-        ra.fast = fast_arith && wave_fft() ? 1 : 0;
+        ra.fast = fast_chain() ? 1 : 0; // (the modes with a free-form fused kernel: none of them can put NaN into the stream)
         if (d.resample && chain->res_stream && chain->ev_ring_free && !only_resample)
             HIPV(hipStreamWaitEvent(st, chain->ev_ring_free, 0));
         if (only_resample) {

@@ -3027,7 +3027,7 @@ __global__ __launch_bounds__(kTileOut) void pv_resample_kernel(const ResArgs a) 
 // reference's operation order needs four multiplies and four adds (~4.5x fewer vector instructions at NR = 8).  The
 // result differs from the reference's by rounding only (~1e-7 relative: one accumulator instead of four, fma).
 // --------------------------------------------------------------------------------------------
-constexpr int kResFastRows = 8;
+constexpr int kResFastRows = 16; // (8 where the batch has fewer rows or the tile does not fit 64 KB of LDS)
 
 template <int kRes, int NR> // 1 = direct sinc table, 2 = cubic-interpolated table
 __global__ __launch_bounds__(kTileOut) void pv_resample_fast_kernel(const ResArgs a) {
@@ -3077,10 +3077,21 @@ __global__ __launch_bounds__(kTileOut) void pv_resample_fast_kernel(const ResArg
         const float4 *__restrict__ T = tab4 + (int)(oe.x >> 16) * (NF + 1);
 #pragma unroll 4
         for (int j = 0; j < NF; ++j) { // NF is a multiple of 4 (resample.c:687)
+            // (PV_EXP_RES: elimination builds for timing only -- bit 0 no sample reads, bit 1 no coefficient reads)
+#if defined(PV_EXP_RES) && (PV_EXP_RES & 2)
+            const float4 c = make_float4(frac, c0, c1, (float)j);
+#else
             const float4 c = T[j];
+#endif
             const float h = __builtin_fmaf(c3, c.w, __builtin_fmaf(c2, c.z, __builtin_fmaf(c1, c.y, c0 * c.x)));
 #pragma unroll
-            for (int r = 0; r < NR; ++r) acc[r] = __builtin_fmaf(x[r * a.lds_floats + j], h, acc[r]);
+            for (int r = 0; r < NR; ++r) {
+#if defined(PV_EXP_RES) && (PV_EXP_RES & 1)
+                acc[r] = __builtin_fmaf(frac + (float)r, h, acc[r]);
+#else
+                acc[r] = __builtin_fmaf(x[r * a.lds_floats + j], h, acc[r]);
+#endif
+            }
         }
     } else {
         const float *t = stab + (oe.x >> 16) * (uint32_t)NF;
@@ -3096,8 +3107,12 @@ __global__ __launch_bounds__(kTileOut) void pv_resample_fast_kernel(const ResArg
         if (r < nr) out[(int64_t)r * a.out_stride_row] = acc[r];
 }
 
-static void launch_resample_fast(const ResArgs &a, hipStream_t st) {
-    constexpr int NR = kResFastRows;
+// (Measured and left out, round 3: NO = 4 consecutive outputs per thread walking the samples of their common span once
+// -- the filter rows padded with zeros so that taps outside 0 .. NF - 1 contribute nothing -- four times fewer sample
+// reads, bit-identical output.  Alone it is faster, 0.255 -> 0.202 ms per launch, its four 16-byte coefficient reads per
+// sample step then being the LDS cost; beside the rotation chain, where the kernel really runs, its 64 KB of LDS per
+// workgroup and low occupancy make it slower, 0.30 -> 0.34-0.38 ms: profiles/r03/resample_elim.txt.)
+template <int NR> static void launch_resample_fast_rows(const ResArgs &a, hipStream_t st) {
     const size_t lds = (size_t)a.tab_bytes + sizeof(float) * (size_t)a.lds_floats * NR;
     const dim3 grid(a.ntiles, (a.rows + NR - 1) / NR);
     static unsigned long long m1 = 0, m2 = 0;
@@ -3108,6 +3123,17 @@ static void launch_resample_fast(const ResArgs &a, hipStream_t st) {
         allow_big_lds_dev(pv_resample_fast_kernel<1, NR>, m1);
         hipLaunchKernelGGL((pv_resample_fast_kernel<1, NR>), grid, dim3(kTileOut), lds, st, a);
     }
+}
+static void launch_resample_fast(const ResArgs &a, hipStream_t st) {
+    static const int rows_env = [] { // AUDIOMOD_PV_RES_ROWS=8|16 (tuning knob)
+        const char *e = getenv("AUDIOMOD_PV_RES_ROWS");
+        return e ? atoi(e) : 0;
+    }();
+    const int want = rows_env ? rows_env : kResFastRows; // (8 -> 16 rows per thread: 0.265 -> 0.255 ms per launch alone, cfg4 -7 st +3 %)
+    if (want >= 16 && a.rows >= 16 && (size_t)a.tab_bytes + sizeof(float) * (size_t)a.lds_floats * 16 <= 64 * 1024)
+        launch_resample_fast_rows<16>(a, st);
+    else
+        launch_resample_fast_rows<8>(a, st);
 }
 
 void launch_resample(const ResArgs &a, hipStream_t st) {
