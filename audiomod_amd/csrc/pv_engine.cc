@@ -340,8 +340,12 @@ struct Core {
     bool wave_fft() const { return d.fft.nc == 1024 || d.fft.nc == 2048; }
     // PV_ARITH_FAST and a free-form fused kernel exists for this configuration (pv_kernels.hip launch_synth_chain):
     // the window-sum denominators are then uploaded as reciprocals
-    bool fast_chain() const {
-        if (!(fast_arith && use_chain && wave_fft())) return false;
+    bool fast_chain() const { return use_chain && fast_capable(); }
+    // ... whatever the path: with PV_ARITH_FAST such a configuration ALWAYS takes the fused path (init), so that what
+    // an engine computes does not depend on how many rows it was created for -- a batch, its host-staged groups and
+    // the single-stream engine run the same kernels and agree bit for bit, as they do under PV_ARITH_EXACT
+    bool fast_capable() const {
+        if (!(fast_arith && wave_fft())) return false;
         SynthArgs sa{};
         sa.tb.nc = d.fft.nc;
         sa.do_freq_comp = d.do_freq_comp ? 1 : 0;
@@ -437,7 +441,7 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     otab_off = (ola_lds_floats + 3) & ~3;
     wacc_pitch = otab_off + 2 * kTileOut;
     lookback = (d.N + tile_span) / d.min_shift + 3;
-    use_chain = chain_wanted() && (chain_required || rows >= kChainMinRows);
+    use_chain = chain_wanted() && (chain_required || rows >= kChainMinRows || fast_capable());
     if (const char *e = getenv("AUDIOMOD_PV_FUSED")) // =2: the fused path whatever the row count
         if (atoi(e) == 2) use_chain = true;
     if (!use_chain && (tile_span + d.N) / d.min_shift + 3 > kMaxTileFrames) {
@@ -1331,7 +1335,10 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
     // +8 % over 16 K with 256 rows; flat beyond), and the planes of such a chunk are a few GB of the 288
     // Round 2, fused path (192 rows and up): 128 K slices per launch, up to 512 per row -- half as many kernel
     // boundaries (each a drain and a refill of the chip): 52.0 vs 52.9 ms per bench step; 768 per row: no further gain.
-    const bool wide = rows >= 192;
+    // Round 3: with PV_ARITH_FAST every wave-FFT configuration that has a free-form kernel takes the fused path at
+    // any row count (Core::fast_capable), and the wide chunks with it (8-95 streams: +5...20 % over the tile path).
+    const bool fast_wave = g_arith == PV_ARITH_FAST && (cfg->fftsize > 1024 && cfg->fftsize <= 4096);
+    const bool wide = rows >= 192 || fast_wave;
     int Tc = (wide ? 131072 : 65536) / (rows > 0 ? rows : 1);
     if (Tc < 16) Tc = 16;
     if (Tc > (wide ? 512 : 256)) Tc = wide ? 512 : 256;
@@ -1695,6 +1702,7 @@ int pv_create(const pv_config *cfg, int device, pv_engine **out) {
     *out = nullptr;
     std::unique_ptr<pv_engine> e(new pv_engine());
     e->core.chain_required = true;
+    e->core.fast_arith = g_arith == PV_ARITH_FAST; // (same kernels as the batch engine: see Core::fast_capable)
     int st = e->core.init(*cfg, device, 1, kStreamChunk);
     if (st != PV_OK) return st;
     Core &c = e->core;
@@ -1858,6 +1866,10 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
             if (c.d.resample && kb > ka) c.build_res_tiles(ka, kb, res_tiles, res_otab);
             while (wden.size() & 3) wden.push_back(1.f), wden_hi.push_back(1.f);
             for (int i = 0; i < 4; ++i) wden.push_back(1.f), wden_hi.push_back(1.f);
+            if (c.fast_chain()) { // the free-form kernel normalises by multiplying
+                for (float &v : wden) v = 1.0f / v;
+                for (float &v : wden_hi) v = 1.0f / v;
+            }
         } else if (kb > ka) {
             st = c.build_tiles(e->recent, e->t_base, tb, ka, kb, (int32_t)e->t_base, tiles, wacc);
             if (st != PV_OK) return fail(st);

@@ -3137,8 +3137,8 @@ static void launch_resample_fast(const ResArgs &a, hipStream_t st) {
 }
 
 void launch_resample(const ResArgs &a, hipStream_t st) {
+    if (a.ntiles <= 0) return; // (a group of dropped slices completes no output)
     if (a.fast) return launch_resample_fast(a, st);
-    if (a.ntiles <= 0) return;
     const size_t lds = (size_t)a.tab_bytes + sizeof(float) * (size_t)a.lds_floats * kResRows;
     const dim3 grid(a.ntiles, (a.rows + kResRows - 1) / kResRows);
     static unsigned long long m1 = 0, m2 = 0;

@@ -448,11 +448,17 @@ def main():
         # (a stage's GB/s is still computed over all of its kernels' durations).
         overlapped = [k for k in ("pv_seq_kernel", "pv_prop_kernel") if batch.pipelined and k in per_kernel]
         main = {k: v for k, v in per_kernel.items() if k not in overlapped}
+        if not main:  # --sample-every 0 (counter passes: no events in the stream): nothing per kernel to report
+            main = {"none": {"avg_ms": float("nan")}}
+            stages["none"] = (0, ["none"])
+            per_stage["none"] = {"GBps": 0.0}
         dom = max(main, key=lambda k: main[k]["avg_ms"])
         dom_stage = next(n for n, (_, ks) in stages.items() if dom in ks and n in per_stage)
         dom_bytes = stages[dom_stage][0]
         achieved = round(dom_bytes * slices_per_launch / (main[dom]["avg_ms"] * 1e-3) / 1e9, 1) \
             if dom_stage != "phase" or not overlapped else per_stage[dom_stage]["GBps"]
+        if dom == "none":
+            achieved = 0.0
         std_geometry = G == 1 and args.streams == 128 and args.config == "cfg2" and args.seconds == 60
         traffic = traffic_db.get(dom) if std_geometry else None
         hbm_real = None

@@ -87,9 +87,13 @@ typedef struct pv_info {
  *   PV_ARITH_EXACT  resynthesis, overlap-add, normalisation and resampling also in the reference's operation order
  *                   (bit-identical to the reference except for the sine / cosine of the resynthesis; ROBOTIC mode
  *                   bit-identical end to end);
- *   PV_ARITH_FAST   the many-stream batch path (pv_batch_*, pv_hostio_* at 192 rows and up) may fuse multiply-adds,
- *                   regroup sums and skip phase wraps there (measured: ~1e-8 RMS against the reference).  The
- *                   single-stream engine (pv_create) and small batches compute as PV_ARITH_EXACT either way. */
+ *   PV_ARITH_FAST   where a free-form kernel exists -- the plain pitch-shift / stretch modes in every core mode and
+ *                   the formant / gender modes, at fft 2048 and 4096 -- resynthesis, normalisation and resampling may
+ *                   fuse multiply-adds, regroup sums, skip phase wraps and use the hardware's sine / cosine
+ *                   (measured: 1e-8 ... 5e-8 RMS against the reference).  Such a configuration then always takes the
+ *                   fused overlap-add path, in the single-stream engine and in batches of any size alike, so every
+ *                   engine runs the same kernels and they agree with each other bit for bit under either setting.
+ *                   Every other mode and size computes as PV_ARITH_EXACT. */
 #define PV_ARITH_FAST 0
 #define PV_ARITH_EXACT 1
 int pv_set_arithmetic(int arith);

@@ -504,7 +504,9 @@ np.savez(sys.argv[1], *outs)
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         files = []
-        for tag, env in (("spec", {}), ("generic", {"AUDIOMOD_PV_SYNTH_GENERIC": "1"})):
+        # (AUDIOMOD_PV_EXACT=1: only the specialisations have a free-form twin; this test is about the exact kernels)
+        for tag, env in (("spec", {"AUDIOMOD_PV_EXACT": "1"}),
+                         ("generic", {"AUDIOMOD_PV_SYNTH_GENERIC": "1", "AUDIOMOD_PV_EXACT": "1"})):
             f = os.path.join(d, tag + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,
                                env=dict(os.environ, **env), timeout=600)
