@@ -1170,9 +1170,12 @@ void launch_seq(const SeqArgs &a, hipStream_t st) {
     }();
     static const int depth = [] { // AUDIOMOD_PV_SEQ_DEPTH=4|8 (tuning knob)
         const char *e = getenv("AUDIOMOD_PV_SEQ_DEPTH");
-        return e ? atoi(e) : 4;
+        return e ? atoi(e) : 0;
     }();
-    const int D = depth <= 4 ? 4 : 8;
+    // Four steps ahead where the kernel shares its CUs with a full batch's other kernels (a deeper ring's LDS then
+    // costs more than its latency cover returns: 0.58 vs 0.38 ms per launch beside the resampling kernel); eight for
+    // small batches, which are bound by this chain and leave the LDS free (20 streams: 10.6 -> 11.0 G samples/s).
+    const int D = depth ? (depth <= 4 ? 4 : 8) : (a.rows <= 96 ? 8 : 4);
     const size_t ring_lds = ((lds + 15) & ~(size_t)15) + (size_t)D * nt * sizeof(PeakRec);
     if (!no_ring && a.PKP <= nt && ring_lds <= 160 * 1024 - 512) {
         static unsigned long long bigr4 = 0, bigr8 = 0;
