@@ -379,20 +379,32 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
     constexpr int J = NC / 128;
     const int lp0 = wf_lane_part<W>(0, lane), lp1 = wf_lane_part<W>(1, lane), lp2 = wf_lane_part<W>(2, lane);
     WfTwRaw<W, 1> raw1;
+    // (PV_EXP_ANA: elimination builds for timing only, results invalid -- bit 0 no butterflies, 1 no LDS exchanges
+    // between the passes, 2 no polar conversion, 3 no plane stores, 4 no peak search)
+#if defined(PV_EXP_ANA) && (PV_EXP_ANA & 1)
+#define PV_ANA_BFLY(x)
+#else
+#define PV_ANA_BFLY(x) x
+#endif
+#if defined(PV_EXP_ANA) && (PV_EXP_ANA & 2)
+#define PV_ANA_XCHG(x)
+#else
+#define PV_ANA_XCHG(x) x
+#endif
     wf_fetch_pass_tw<W, 1>(raw1, lane, twl);
-    wf_apply_pass_stages<W, 0, false>(v, T0);
-    wf_store<W, 0>(lds, v, lp0);
+    PV_ANA_BFLY((wf_apply_pass_stages<W, 0, false>(v, T0)));
+    PV_ANA_XCHG((wf_store<W, 0>(lds, v, lp0)));
     wave_sync();
-    wf_load<W, 1>(lds, v, lp1);
+    PV_ANA_XCHG((wf_load<W, 1>(lds, v, lp1)));
     wf_unpack_pass_tw<W, 1>(T1, raw1);
-    wf_apply_pass_stages<W, 1, false>(v, T1);
+    PV_ANA_BFLY((wf_apply_pass_stages<W, 1, false>(v, T1)));
     WfTwRaw<W, 2> raw2;
     wf_fetch_pass_tw<W, 2>(raw2, lane, twl);
-    wf_store<W, 1>(lds, v, lp1);
+    PV_ANA_XCHG((wf_store<W, 1>(lds, v, lp1)));
     wave_sync();
-    wf_load<W, 2>(lds, v, lp2);
+    PV_ANA_XCHG((wf_load<W, 2>(lds, v, lp2)));
     wf_unpack_pass_tw<W, 2>(T2, raw2);
-    wf_apply_pass_stages<W, 2, false>(v, T2);
+    PV_ANA_BFLY((wf_apply_pass_stages<W, 2, false>(v, T2)));
     cf sw[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) sw[j] = stw[lane + 64 * j];
@@ -484,6 +496,12 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
         const float mn = __builtin_fminf(__builtin_fminf(pv_min3_abs(c01.x, c01.y, c01.z), pv_min3_abs(c01.w, c23.x, c23.y)),
                                          __builtin_fminf(__builtin_fabsf(c23.z), __builtin_fabsf(c23.w)));
         const bool in_range = mx < 0x1p63f && mn >= 0x1p-48f;
+#if defined(PV_EXP_ANA) && (PV_EXP_ANA & 4)
+        if (true) {
+            m4 = make_float4(a0, a1, a2, a3);
+            p4 = make_float4(c01.y + mx, c01.w + mn, c23.y, c23.w);
+        } else
+#endif
         if (__builtin_amdgcn_ballot_w64(!in_range) == 0) {
             m4 = make_float4(pv_sqrt_safe(a0), pv_sqrt_safe(a1), pv_sqrt_safe(a2), pv_sqrt_safe(a3));
             p4.x = pv_atan2f_fd_tab<true>(c01.y, c01.x, atab);
@@ -498,8 +516,12 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
             p4.w = pv_atan2f_fd_tab<false>(c23.w, c23.z, atab);
         }
         if (q == 0 && lane == 0) p4.x = edge_ph, m4.x = edge_mag;
+#if !(defined(PV_EXP_ANA) && (PV_EXP_ANA & 8))
         *reinterpret_cast<float4 *>(ph + i4) = p4;
         *reinterpret_cast<float4 *>(mag + i4) = m4;
+#else
+        if (p4.x == 12345.678f) *reinterpret_cast<float4 *>(ph + i4) = p4; // (keeps the values alive)
+#endif
         *reinterpret_cast<float4 *>(smag + i4) = m4;
     }
     if (lane == 1) {
@@ -508,6 +530,10 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
         smag[NC] = edge_mag;
     }
     wave_sync();
+#if defined(PV_EXP_ANA) && (PV_EXP_ANA & 16)
+    if (lane == 0) a.npk[plane] = 100;
+    return;
+#endif
     if (!a.find_peaks) return;
     // ordered list first into LDS (behind the magnitudes), then out in whole 32-bit words: three coalesced
     // stores per lane instead of one sparsely populated 16-bit store per group of 64 bins
