@@ -5,6 +5,7 @@
 // Build: g++ -O2 -std=c++17 -ffp-contract=off -Iinclude -Iaudiomod_amd/csrc tests/native/host_wavefft.cc \
 //            audiomod_amd/csrc/pv_plan.cc -o /tmp/host_wavefft
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -126,8 +127,47 @@ template <int NC, bool INV> static int check(unsigned seed) {
         const cf g = lds[W::pad(e)];
         if (memcmp(&g, &want[e], sizeof(cf)) != 0) ++bad;
     }
-    printf("NC %d inv %d: %s (%d mismatches; lane table %d + %d slots)\n", NC, (int)INV, bad ? "FAIL" : "bit-exact", bad,
-           wf_pass_slots<W>(1), wf_pass_slots<W>(2));
+    // ... and the free-form (PV_ARITH_FAST) stages: same transform, fma products and literal twiddles where the twiddle
+    // index lives in register bits -- equal to the exact result up to rounding (relative to the spectrum's RMS)
+    std::fill(lds.begin(), lds.end(), cf{0, 0});
+    for (int lane = 0; lane < 64; ++lane) {
+        cf v[W::R];
+        WfTw<W> T;
+        const int lp = wf_lane_part<W>(0, lane);
+        for (int r = 0; r < W::R; ++r) v[r] = in[wf_src_of<W>(lp | wf_reg_part<W>(0, r))];
+        if (!wf_pass_all_const<W, 0>()) wf_load_pass_tw<W, 0>(T, lane, tw.data());
+        wf_apply_pass_stages_fast<W, 0, INV>(v, T);
+        wf_store<W, 0>(lds.data(), v, lp);
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+        cf v[W::R];
+        WfTw<W> T;
+        const int lp = wf_lane_part<W>(1, lane);
+        wf_load<W, 1>(lds.data(), v, lp);
+        wf_load_pass_tw<W, 1>(T, lane, tw.data());
+        wf_apply_pass_stages_fast<W, 1, INV>(v, T);
+        wf_store<W, 1>(lds.data(), v, lp);
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+        cf v[W::R];
+        WfTw<W> T;
+        const int lp = wf_lane_part<W>(2, lane);
+        wf_load<W, 2>(lds.data(), v, lp);
+        wf_load_pass_tw<W, 2>(T, lane, tw.data());
+        wf_apply_pass_stages_fast<W, 2, INV>(v, T);
+        wf_store<W, 2>(lds.data(), v, lp);
+    }
+    double err = 0, ref = 0;
+    for (int e = 0; e < NC; ++e) {
+        const cf g = lds[W::pad(e)];
+        err += ((double)g.x - want[e].x) * ((double)g.x - want[e].x) + ((double)g.y - want[e].y) * ((double)g.y - want[e].y);
+        ref += (double)want[e].x * want[e].x + (double)want[e].y * want[e].y;
+    }
+    const double rel = std::sqrt(err / ref);
+    if (!(rel < 2e-7)) ++bad;
+    printf("NC %d inv %d: %s (%d mismatches; lane table %d + %d slots; free-form stages: relative RMS %.2e, pass 0 %s)\n", NC,
+           (int)INV, bad ? "FAIL" : "bit-exact", bad, wf_pass_slots<W>(1), wf_pass_slots<W>(2), rel,
+           wf_pass_all_const<W, 0>() ? "all literal twiddles" : "fetched twiddles");
     return bad != 0;
 }
 
