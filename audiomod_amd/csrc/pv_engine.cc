@@ -337,7 +337,7 @@ struct Core {
         const char *sl = getenv("AUDIOMOD_PV_STREAM_LAUNCHES"); // the opt-in one-workgroup streaming kernel chains
         return !(sl && strcmp(sl, "single") == 0);               // the separate stages' device functions
     }
-    bool wave_fft() const { return d.fft.nc == 1024 || d.fft.nc == 2048; }
+    bool wave_fft() const { return d.fft.nc == 512 || d.fft.nc == 1024 || d.fft.nc == 2048; } // fft 1024 / 2048 / 4096
     // PV_ARITH_FAST and a free-form fused kernel exists for this configuration (pv_kernels.hip launch_synth_chain):
     // the window-sum denominators are then uploaded as reciprocals
     bool fast_chain() const { return use_chain && fast_capable(); }
@@ -526,13 +526,16 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
     if ((st = up2(tw_fwd, d.fft.tw_fwd)) != PV_OK) return st;
     if ((st = up2(tw_inv, d.fft.tw_inv)) != PV_OK) return st;
     if ((st = up2(st_fwd, d.fft.st_fwd)) != PV_OK) return st;
-    if (d.fft.nc == 1024 || d.fft.nc == 2048) { // lane-major twiddle tables of the wave-per-frame kernels
+    if (wave_fft()) { // lane-major twiddle tables of the wave-per-frame kernels
         auto lane_table = [&](const std::vector<cpx> &tw, DevBuf<float4> &dst) -> int {
             std::vector<cf> twc(tw.size());
             for (size_t i = 0; i < tw.size(); ++i) twc[i] = cf{tw[i].r, tw[i].i};
-            const int entries = d.fft.nc == 1024 ? wf_lane_table_entries<WF<1024>>() : wf_lane_table_entries<WF<2048>>();
+            const int entries = d.fft.nc == 512    ? wf_lane_table_entries<WF<512>>()
+                                : d.fft.nc == 1024 ? wf_lane_table_entries<WF<1024>>()
+                                                   : wf_lane_table_entries<WF<2048>>();
             std::vector<cf> out(2 * (size_t)entries * 64);
-            if (d.fft.nc == 1024) wf_build_lane_table<WF<1024>>(twc.data(), out.data());
+            if (d.fft.nc == 512) wf_build_lane_table<WF<512>>(twc.data(), out.data());
+            else if (d.fft.nc == 1024) wf_build_lane_table<WF<1024>>(twc.data(), out.data());
             else wf_build_lane_table<WF<2048>>(twc.data(), out.data());
             std::vector<float4> o4((size_t)entries * 64);
             for (size_t i = 0; i < o4.size(); ++i) o4[i] = make_float4(out[2 * i].x, out[2 * i].y, out[2 * i + 1].x, out[2 * i + 1].y);
@@ -1337,7 +1340,7 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
     // boundaries (each a drain and a refill of the chip): 52.0 vs 52.9 ms per bench step; 768 per row: no further gain.
     // Round 3: with PV_ARITH_FAST every wave-FFT configuration that has a free-form kernel takes the fused path at
     // any row count (Core::fast_capable), and the wide chunks with it (8-95 streams: +5...20 % over the tile path).
-    const bool fast_wave = g_arith == PV_ARITH_FAST && (cfg->fftsize > 1024 && cfg->fftsize <= 4096);
+    const bool fast_wave = g_arith == PV_ARITH_FAST && (cfg->fftsize > 512 && cfg->fftsize <= 4096);
     const bool wide = rows >= 192 || fast_wave;
     int Tc = (wide ? 131072 : 65536) / (rows > 0 ? rows : 1);
     if (Tc < 16) Tc = 16;

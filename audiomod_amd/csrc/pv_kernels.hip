@@ -340,16 +340,17 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
                 xt = xb[64 * Q];
                 wt = wb[64 * Q];
             }
+            constexpr int QS = Q < 8 ? Q : 8;
 #pragma unroll
-            for (int q0 = 0; q0 < Q; q0 += 8) {
-                float4 xq[8], wq[8];
+            for (int q0 = 0; q0 < Q; q0 += QS) {
+                float4 xq[QS], wq[QS];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < QS; ++q) {
                     xq[q] = xb[lane + 64 * (q0 + q)];
                     wq[q] = wb[lane + 64 * (q0 + q)];
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
+                for (int q = 0; q < QS; ++q)
                     stage4[lane + 64 * (q0 + q)] =
                         make_float4(xq[q].x * wq[q].x, xq[q].y * wq[q].y, xq[q].z * wq[q].z, xq[q].w * wq[q].w);
             }
@@ -405,11 +406,22 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
     PV_ANA_XCHG((wf_load<W, 2>(lds, v, lp2)));
     wf_unpack_pass_tw<W, 2>(T2, raw2);
     PV_ANA_BFLY((wf_apply_pass_stages<W, 2, false>(v, T2)));
+    if constexpr (W::NPASS == 4) { // (512 points: the last radix-4 stage is a pass of its own)
+        const int lp3 = wf_lane_part<W>(3, lane);
+        WfTwRaw<W, 3> raw3;
+        wf_fetch_pass_tw<W, 3>(raw3, lane, twl);
+        PV_ANA_XCHG((wf_store<W, 2>(lds, v, lp2)));
+        wave_sync();
+        PV_ANA_XCHG((wf_load<W, 3>(lds, v, lp3)));
+        wf_unpack_pass_tw<W, 3>(T2, raw3);
+        PV_ANA_BFLY((wf_apply_pass_stages<W, 3, false>(v, T2)));
+    }
     cf sw[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) sw[j] = stw[lane + 64 * j];
     const cf swmid = stw[NC / 2];
-    wf_store<W, 2>(lds, v, lp2);
+    if constexpr (W::NPASS == 4) wf_store<W, 3>(lds, v, wf_lane_part<W>(3, lane));
+    else wf_store<W, 2>(lds, v, lp2);
     wave_sync();
 
     // real-FFT split (kiss_fftr.c:91-120) + polar (FFT.cc:2623-2630); lane handles k = lane + 64 j and NC - k
@@ -600,6 +612,13 @@ template <typename K> static void allow_big_lds_dev(K kernel, unsigned long long
 }
 
 void launch_analyze(const AnalyzeArgs &a, hipStream_t st) {
+    if (a.tb.nc == 512) { // fft 1024: four passes (pv_wavefft.h WF<512>)
+        constexpr int WPB = 1;
+        const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
+        hipLaunchKernelGGL((pv_analyze_wave_kernel<512, WPB>), dim3(grid), dim3(64 * WPB),
+                           WPB * WF<512>::LDS_CF * sizeof(cf) + 4 * PV_ATAN_BLOB_WORDS, st, a);
+        return;
+    }
     if (a.tb.nc == 1024 || a.tb.nc == 2048) {
         if (a.tb.nc == 1024) {
             constexpr int WPB = 1; // one frame per workgroup: nothing couples the waves, and 8.6 KB of LDS each
@@ -1771,15 +1790,27 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
         wf_unpack_pass_tw<W, 2>(T2, raw2);
         if (kFast) wf_apply_pass_stages_fast<W, 2, true>(v, T2);
         else wf_apply_pass_stages<W, 2, true>(v, T2);
-        if constexpr (kSink == 1) {
+        constexpr int PL = W::NPASS - 1; // the last pass
+        const int lpl = wf_lane_part<W>(PL, lane);
+        if constexpr (W::NPASS == 4) { // (512 points: the last radix-4 stage is a pass of its own)
+            WfTwRaw<W, 3> raw3;
+            wf_fetch_pass_tw<W, 3>(raw3, lane, twl);
             wf_store<W, 2>(lds, v, lp2);
+            wave_sync();
+            wf_load<W, 3>(lds, v, lpl);
+            wf_unpack_pass_tw<W, 3>(T1, raw3);
+            if (kFast) wf_apply_pass_stages_fast<W, 3, true>(v, T1);
+            else wf_apply_pass_stages<W, 3, true>(v, T1);
+        }
+        if constexpr (kSink == 1) {
+            wf_store<W, PL>(lds, v, lpl);
             wave_sync();
             return;
         }
         float4 ww[NC / 128];
 #pragma unroll
         for (int j = 0; j < NC / 128; ++j) ww[j] = *reinterpret_cast<const float4 *>(w + 4 * (lane + 64 * j));
-        wf_store<W, 2>(lds, v, lp2);
+        wf_store<W, PL>(lds, v, lpl);
         wave_sync();
         // 5. ifftshift + synthesis window (phasevocoderimpl.h:183-198): four consecutive samples per lane and
         //    store (the stores are issue-bound: half as many 16-byte ones beat twice as many 8-byte ones)
@@ -1870,6 +1901,16 @@ static bool synth_generic_only() {
 }
 
 void launch_synth(const SynthArgs &a, hipStream_t st) {
+    if (a.tb.nc == 512) { // fft 1024 (round 3): the phase-locked plain specialisation, else the all-modes kernel
+        constexpr int WPB = 1;
+        const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
+        const size_t lds = WPB * WF<512>::LDS_CF * sizeof(cf);
+        const bool plain = !a.do_freq_comp && a.voc_band_len < 0 && !a.robotic && !a.passthru && !a.whisper &&
+                           !synth_generic_only();
+        if (plain && a.coremode == 1) hipLaunchKernelGGL((pv_synth_wave_kernel<512, WPB, 1>), dim3(grid), dim3(64 * WPB), lds, st, a);
+        else hipLaunchKernelGGL((pv_synth_wave_kernel<512, WPB>), dim3(grid), dim3(64 * WPB), lds, st, a);
+        return;
+    }
     if (a.tb.nc == 1024 || a.tb.nc == 2048) {
         if (a.tb.nc == 1024) {
             constexpr int WPB = 1;
@@ -2784,7 +2825,7 @@ __device__ __forceinline__ void chain_slice_tail(const ChainArgs &c_in, const Ch
 // (the all-modes variant -- frequency compression, vocoder, ... -- needs ~150 VGPRs where the plain ones fit 128:
 // compiled for twelve waves per workgroup, three per SIMD, instead of spilling)
 template <int NC, int kPlainCore, int kRes, bool kFast = false>
-__global__ __launch_bounds__(NC == 1024 ? ((kPlainCore < 0 || kPlainCore == 3) ? 768 : 1024) : 512) void pv_synth_chain_kernel(
+__global__ __launch_bounds__(NC <= 1024 ? ((kPlainCore < 0 || kPlainCore == 3) ? 768 : 1024) : 512) void pv_synth_chain_kernel(
     const SynthArgs s, const ChainArgs c) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
@@ -2877,13 +2918,19 @@ template <int kRes> __global__ __launch_bounds__(1024) void pv_frames_chain_kern
 }
 
 size_t chain_lds_bytes(const ChainArgs &a, int nc_wave) {
-    const size_t per_wave = nc_wave == 1024 ? WF<1024>::LDS_CF * sizeof(cf)
+    const size_t per_wave = nc_wave == 512    ? WF<512>::LDS_CF * sizeof(cf)
+                            : nc_wave == 1024 ? WF<1024>::LDS_CF * sizeof(cf)
                             : nc_wave == 2048 ? WF<2048>::LDS_CF * sizeof(cf) : 0;
     return (size_t)a.waves * per_wave + chain_shared_bytes(a);
 }
 
 template <int NC, int kPlainCore> static void launch_synth_chain_res(const SynthArgs &s, const ChainArgs &c, hipStream_t st) {
     const size_t lds = chain_lds_bytes(c, NC);
+    constexpr int kMaxThreads = NC <= 1024 ? ((kPlainCore < 0 || kPlainCore == 3) ? 768 : 1024) : 512; // the kernel's launch bounds
+    if (64 * c.waves > kMaxThreads) { // (never: Core::init sizes chain_waves by the same rule; a launch beyond the bounds faults)
+        fprintf(stderr, "audiomod_pv: fused kernel launch of %d waves exceeds its bounds (%d threads): not launched\n", c.waves, kMaxThreads);
+        return;
+    }
     const dim3 grid(c.rows, c.runs), block(64 * c.waves);
     static unsigned long long m0 = 0, m1 = 0, f0 = 0, f1 = 0;
     if constexpr (kPlainCore >= 0) { // the specialisations have a free-form (PV_ARITH_FAST) twin
@@ -2913,7 +2960,8 @@ bool synth_chain_has_fast(const SynthArgs &s) {
                        !synth_generic_only() && s.coremode >= 0 && s.coremode <= 2;
     const bool fc_locked = s.do_freq_comp && s.voc_band_len < 0 && !s.robotic && !s.passthru && !s.whisper &&
                            !synth_generic_only() && s.coremode == 1;
-    return (s.tb.nc == 1024 && (plain || fc_locked)) || (s.tb.nc == 2048 && plain);
+    return (s.tb.nc == 1024 && (plain || fc_locked)) || (s.tb.nc == 2048 && plain) ||
+           (s.tb.nc == 512 && plain);
 }
 
 void launch_synth_chain(const SynthArgs &s, const ChainArgs &c, hipStream_t st) {
@@ -2921,7 +2969,12 @@ void launch_synth_chain(const SynthArgs &s, const ChainArgs &c, hipStream_t st) 
                        !synth_generic_only() && s.coremode >= 0 && s.coremode <= 2;
     const bool fc_locked = s.do_freq_comp && s.voc_band_len < 0 && !s.robotic && !s.passthru && !s.whisper &&
                            !synth_generic_only() && s.coremode == 1;
-    if (s.tb.nc == 1024) {
+    if (s.tb.nc == 512) { // fft 1024: the plain specialisations (sixteen waves, as the engine sizes the launch), else all modes
+        if (plain && s.coremode == 1) launch_synth_chain_res<512, 1>(s, c, st);
+        else if (plain && s.coremode == 0) launch_synth_chain_res<512, 0>(s, c, st);
+        else if (plain) launch_synth_chain_res<512, 2>(s, c, st);
+        else launch_synth_chain_res<512, -1>(s, c, st);
+    } else if (s.tb.nc == 1024) {
         if (fc_locked) launch_synth_chain_res<1024, 3>(s, c, st);
         else if (plain && s.coremode == 1) launch_synth_chain_res<1024, 1>(s, c, st);
         else if (plain && s.coremode == 0) launch_synth_chain_res<1024, 0>(s, c, st);
@@ -3252,7 +3305,8 @@ bool stream_kernel_supported(const StreamArgs &s) {
 // the kernels that contain it have no static LDS (their dynamic LDS then starts at 0).  The engine asks once per
 // device, at creation.
 bool lds_starts_at_zero() {
-    const void *ks[] = {reinterpret_cast<const void *>(pv_analyze_wave_kernel<1024, 1>),
+    const void *ks[] = {reinterpret_cast<const void *>(pv_analyze_wave_kernel<512, 1>),
+                        reinterpret_cast<const void *>(pv_analyze_wave_kernel<1024, 1>),
                         reinterpret_cast<const void *>(pv_analyze_wave_kernel<2048, 1>),
                         reinterpret_cast<const void *>(pv_stream_kernel<1024>),
                         reinterpret_cast<const void *>(pv_stream_kernel<2048>)};

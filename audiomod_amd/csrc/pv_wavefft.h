@@ -44,13 +44,28 @@ PV_HD cf wf_sub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
 
 template <int NC> struct WF;
 
+// Round 3: 512 complex points (fft 1024), eight elements per lane.  kissfft's stages for 512 are 2, 4, 4, 4, 4; with
+// three register bits per pass a radix-4 stage fills a pass on its own from the second one on: FOUR passes (NPASS).
+template <> struct WF<512> {
+    static constexpr int N_C = 512, LOG = 9, R = 8, RB = 3, NSTAGE = 5, NPASS = 4;
+    static constexpr int st_radix[6] = {2, 4, 4, 4, 4, 0};
+    static constexpr int st_bit[6] = {0, 1, 3, 5, 7, 0};
+    static constexpr int st_pass[6] = {0, 0, 1, 2, 3, 0};
+    static constexpr int regpos[4][5] = {{0, 1, 2, 0, 0}, {3, 4, 5, 0, 0}, {5, 6, 7, 0, 0}, {6, 7, 8, 0, 0}};
+    static constexpr int lanepos[4][6] = {{3, 4, 5, 6, 7, 8}, {0, 1, 2, 6, 7, 8}, {0, 1, 2, 3, 4, 8}, {0, 1, 2, 3, 4, 5}};
+    // e = b + 2 (d1 + 4 d2 + 16 d3 + 64 d4)  <-  src = d4 + 4 d3 + 16 d2 + 64 d1 + 256 b
+    static constexpr int srcbit[11] = {8, 6, 7, 4, 5, 2, 3, 0, 1, 0, 0};
+    static PV_HD int pad(int e) { return e + (e >> 4); }
+    static constexpr int LDS_CF = 512 + 32 + 8;
+};
+
 template <> struct WF<1024> {
-    static constexpr int N_C = 1024, LOG = 10, R = 16, RB = 4, NSTAGE = 5;
+    static constexpr int N_C = 1024, LOG = 10, R = 16, RB = 4, NSTAGE = 5, NPASS = 3;
     static constexpr int st_radix[6] = {4, 4, 4, 4, 4, 0};
     static constexpr int st_bit[6] = {0, 2, 4, 6, 8, 0};
     static constexpr int st_pass[6] = {0, 0, 1, 1, 2, 0};
-    static constexpr int regpos[3][5] = {{0, 1, 2, 3, 0}, {4, 5, 6, 7, 0}, {6, 7, 8, 9, 0}};
-    static constexpr int lanepos[3][6] = {{4, 5, 6, 7, 8, 9}, {0, 1, 2, 3, 8, 9}, {0, 1, 2, 3, 4, 5}};
+    static constexpr int regpos[4][5] = {{0, 1, 2, 3, 0}, {4, 5, 6, 7, 0}, {6, 7, 8, 9, 0}, {0, 0, 0, 0, 0}};
+    static constexpr int lanepos[4][6] = {{4, 5, 6, 7, 8, 9}, {0, 1, 2, 3, 8, 9}, {0, 1, 2, 3, 4, 5}, {0, 0, 0, 0, 0, 0}};
     // kissfft's leaf copy: e = d0 + 4 d1 + 16 d2 + 64 d3 + 256 d4  <-  src = d4 + 4 d3 + 16 d2 + 64 d1 + 256 d0
     static constexpr int srcbit[11] = {8, 9, 6, 7, 4, 5, 2, 3, 0, 1, 0};
     static PV_HD int pad(int e) { return e + (e >> 4); }
@@ -58,12 +73,12 @@ template <> struct WF<1024> {
 };
 
 template <> struct WF<2048> {
-    static constexpr int N_C = 2048, LOG = 11, R = 32, RB = 5, NSTAGE = 6;
+    static constexpr int N_C = 2048, LOG = 11, R = 32, RB = 5, NSTAGE = 6, NPASS = 3;
     static constexpr int st_radix[6] = {2, 4, 4, 4, 4, 4};
     static constexpr int st_bit[6] = {0, 1, 3, 5, 7, 9};
     static constexpr int st_pass[6] = {0, 0, 0, 1, 1, 2};
-    static constexpr int regpos[3][5] = {{0, 1, 2, 3, 4}, {0, 5, 6, 7, 8}, {0, 7, 8, 9, 10}};
-    static constexpr int lanepos[3][6] = {{5, 6, 7, 8, 9, 10}, {1, 2, 3, 4, 9, 10}, {1, 2, 3, 4, 5, 6}};
+    static constexpr int regpos[4][5] = {{0, 1, 2, 3, 4}, {0, 5, 6, 7, 8}, {0, 7, 8, 9, 10}, {0, 0, 0, 0, 0}};
+    static constexpr int lanepos[4][6] = {{5, 6, 7, 8, 9, 10}, {1, 2, 3, 4, 9, 10}, {1, 2, 3, 4, 5, 6}, {0, 0, 0, 0, 0, 0}};
     // e = b + 2 (d1 + 4 d2 + 16 d3 + 64 d4 + 256 d5)  <-  src = d5 + 4 d4 + 16 d3 + 64 d2 + 256 d1 + 1024 b
     static constexpr int srcbit[11] = {10, 8, 9, 6, 7, 4, 5, 2, 3, 0, 1};
     static PV_HD int pad(int e) { return e + (e >> 4) + (e >> 8); }
@@ -238,14 +253,23 @@ template <class W> constexpr int wf_slot_in_pass(int pass, int s_want, int r_wan
 }
 template <class W> constexpr int wf_pass_slots(int pass) { return wf_slot_in_pass<W>(pass, W::NSTAGE, 0, 0); }
 template <class W> constexpr int wf_pass_entries(int pass) { return (wf_pass_slots<W>(pass) + 1) / 2; } // float4s
-template <class W, int P> constexpr int wf_pass_base4() { return P <= 1 ? 0 : wf_pass_entries<W>(1); }
-template <class W> constexpr int wf_lane_table_entries() { return wf_pass_entries<W>(1) + wf_pass_entries<W>(2); }
+template <class W, int P> constexpr int wf_pass_base4() {
+    int b = 0;
+    for (int q = 1; q < P; ++q) b += wf_pass_entries<W>(q);
+    return b;
+}
+template <class W> constexpr int wf_lane_table_entries() {
+    int n = 0;
+    for (int q = 1; q < W::NPASS; ++q) n += wf_pass_entries<W>(q);
+    return n;
+}
 
 // host: fill out[(entry * 64 + lane) * 2 + (slot & 1)] for passes 1 and 2 (out: 2 * entries * 64 values)
 template <class W> inline void wf_build_lane_table(const cf *tw, cf *out) {
     for (int i = 0; i < 2 * wf_lane_table_entries<W>() * 64; ++i) out[i] = cf{0.f, 0.f};
-    for (int pass = 1; pass <= 2; ++pass) {
-        const int base4 = pass == 1 ? 0 : wf_pass_entries<W>(1);
+    for (int pass = 1; pass < W::NPASS; ++pass) {
+        int base4 = 0;
+        for (int q = 1; q < pass; ++q) base4 += wf_pass_entries<W>(q);
         for (int s = 0; s < W::NSTAGE; ++s) {
             if (W::st_pass[s] != pass) continue;
             const int eb = W::st_bit[s], radix = W::st_radix[s], m = 1 << eb;

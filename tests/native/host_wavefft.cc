@@ -64,6 +64,8 @@ template <int NC, bool INV> static int check(unsigned seed) {
     }
     for (int lane = 0; lane < 64; ++lane) { cf v[W::R]; wf_fft_pass<W, 1, INV>(v, lane, lds.data(), tw.data()); }
     for (int lane = 0; lane < 64; ++lane) { cf v[W::R]; wf_fft_pass<W, 2, INV>(v, lane, lds.data(), tw.data()); }
+    if constexpr (W::NPASS == 4)
+        for (int lane = 0; lane < 64; ++lane) { cf v[W::R]; wf_fft_pass<W, 3, INV>(v, lane, lds.data(), tw.data()); }
     for (int e = 0; e < NC; ++e) {
         const cf g = lds[W::pad(e)];
         if (memcmp(&g, &want[e], sizeof(cf)) != 0) ++bad;
@@ -90,6 +92,13 @@ template <int NC, bool INV> static int check(unsigned seed) {
         wf_load_pass_tw<W, 2>(T, lane, tw.data());
         wf_fft_pass_tw<W, 2, INV>(v, lane, lds.data(), T);
     }
+    if constexpr (W::NPASS == 4)
+        for (int lane = 0; lane < 64; ++lane) {
+            cf v[W::R];
+            WfTw<W> T;
+            wf_load_pass_tw<W, 3>(T, lane, tw.data());
+            wf_fft_pass_tw<W, 3, INV>(v, lane, lds.data(), T);
+        }
     for (int e = 0; e < NC; ++e) {
         const cf g = lds[W::pad(e)];
         if (memcmp(&g, &want[e], sizeof(cf)) != 0) ++bad;
@@ -123,6 +132,15 @@ template <int NC, bool INV> static int check(unsigned seed) {
         wf_unpack_pass_tw<W, 2>(T, raw);
         wf_fft_pass_tw<W, 2, INV>(v, lane, lds.data(), T);
     }
+    if constexpr (W::NPASS == 4)
+        for (int lane = 0; lane < 64; ++lane) {
+            cf v[W::R];
+            WfTw<W> T;
+            WfTwRaw<W, 3> raw;
+            wf_fetch_pass_tw<W, 3>(raw, lane, tab2);
+            wf_unpack_pass_tw<W, 3>(T, raw);
+            wf_fft_pass_tw<W, 3, INV>(v, lane, lds.data(), T);
+        }
     for (int e = 0; e < NC; ++e) {
         const cf g = lds[W::pad(e)];
         if (memcmp(&g, &want[e], sizeof(cf)) != 0) ++bad;
@@ -157,6 +175,16 @@ template <int NC, bool INV> static int check(unsigned seed) {
         wf_apply_pass_stages_fast<W, 2, INV>(v, T);
         wf_store<W, 2>(lds.data(), v, lp);
     }
+    if constexpr (W::NPASS == 4)
+        for (int lane = 0; lane < 64; ++lane) {
+            cf v[W::R];
+            WfTw<W> T;
+            const int lp = wf_lane_part<W>(3, lane);
+            wf_load<W, 3>(lds.data(), v, lp);
+            wf_load_pass_tw<W, 3>(T, lane, tw.data());
+            wf_apply_pass_stages_fast<W, 3, INV>(v, T);
+            wf_store<W, 3>(lds.data(), v, lp);
+        }
     double err = 0, ref = 0;
     for (int e = 0; e < NC; ++e) {
         const cf g = lds[W::pad(e)];
@@ -165,14 +193,16 @@ template <int NC, bool INV> static int check(unsigned seed) {
     }
     const double rel = std::sqrt(err / ref);
     if (!(rel < 2e-7)) ++bad;
-    printf("NC %d inv %d: %s (%d mismatches; lane table %d + %d slots; free-form stages: relative RMS %.2e, pass 0 %s)\n", NC,
-           (int)INV, bad ? "FAIL" : "bit-exact", bad, wf_pass_slots<W>(1), wf_pass_slots<W>(2), rel,
+    printf("NC %d inv %d: %s (%d mismatches; lane table %d + %d (+ %d) slots; free-form stages: relative RMS %.2e, pass 0 %s)\n", NC,
+           (int)INV, bad ? "FAIL" : "bit-exact", bad, wf_pass_slots<W>(1), wf_pass_slots<W>(2), W::NPASS == 4 ? wf_pass_slots<W>(3) : 0, rel,
            wf_pass_all_const<W, 0>() ? "all literal twiddles" : "fetched twiddles");
     return bad != 0;
 }
 
 int main() {
     int rc = 0;
+    rc |= check<512, false>(5);
+    rc |= check<512, true>(6);
     rc |= check<1024, false>(1);
     rc |= check<1024, true>(2);
     rc |= check<2048, false>(3);

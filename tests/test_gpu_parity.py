@@ -791,3 +791,40 @@ def test_fast_arithmetic_of_the_batch_path_stays_within_the_contract(kw):
         r = rms(outs[E.ARITH_FAST][s], want)
         assert r <= 1e-6, r
     assert rms(outs[E.ARITH_FAST], outs[E.ARITH_EXACT]) <= 1e-6
+
+
+FFT1024 = [dict(semitones=4.0), dict(semitones=2.0, coremode=0), dict(semitones=2.0, coremode=2),
+           dict(mode="time_stretch", time_ratio=1.5, flush=False), dict(mode="formant_pitchshift", semitones=5.0),
+           dict(mode="robotic"), dict(mode="whisper"), dict(mode="vocoder"), dict(mode="formant_cepstral", semitones=3.0)]
+
+
+@pytest.mark.parametrize("arith", ["fast", "exact"])
+@pytest.mark.parametrize("kw", FFT1024, ids=[str(i) for i in range(len(FFT1024))])
+def test_fft1024_runs_through_the_wave_per_frame_kernels(kw, arith):
+    """Round 3: 1024-point frames (512 complex points, kissfft stages 2 4 4 4 4) have a wave-per-frame transform too --
+    four passes of eight elements per lane (pv_wavefft.h WF<512>; the core is checked bit for bit on the host,
+    tests/native/host_wavefft.cc) -- and with it the fused overlap-add path and, for the plain modes, the free-form
+    kernels.  Streaming and batch API against the oracle under both arithmetic settings; ROBOTIC bit for bit; the batch
+    equal to the stream bit for bit."""
+    import torch
+    kw = dict(kw, fftsize=1024)
+    flush = kw.pop("flush", True)
+    x = signals.voice(30000, 2, seed=77)
+    prev = E.get_arithmetic()
+    try:
+        E.set_arithmetic(E.ARITH_FAST if arith == "fast" else E.ARITH_EXACT)
+        want, wc, _ = O.run_offline(x, flush=flush, **kw)
+        got, gc = E.run_offline(x, flush=flush, **kw)
+        S = 5
+        b = E.Batch(S, x.shape[1], channels=2, flush=flush, **kw)
+        o = b.run(torch.from_numpy(np.stack([x] * S)).cuda())
+        torch.cuda.synchronize()
+        o = o.cpu().numpy()
+        b.close()
+    finally:
+        E.set_arithmetic(prev)
+    assert gc == wc and got.shape == want.shape
+    assert rms(got, want) <= RMS_TOL and rms(o[S - 1], want) <= RMS_TOL
+    assert bits_equal(o[0], got) and bits_equal(o[S - 1], got)
+    if kw.get("mode") == "robotic":
+        assert bits_equal(got, want.astype(np.float32))
