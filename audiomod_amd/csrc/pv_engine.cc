@@ -337,7 +337,7 @@ struct Core {
         const char *sl = getenv("AUDIOMOD_PV_STREAM_LAUNCHES"); // the opt-in one-workgroup streaming kernel chains
         return !(sl && strcmp(sl, "single") == 0);               // the separate stages' device functions
     }
-    bool wave_fft() const { return d.fft.nc == 512 || d.fft.nc == 1024 || d.fft.nc == 2048; } // fft 1024 / 2048 / 4096
+    bool wave_fft() const { return d.fft.nc == 256 || d.fft.nc == 512 || d.fft.nc == 1024 || d.fft.nc == 2048; } // fft 512 ... 4096
     // PV_ARITH_FAST and a free-form fused kernel exists for this configuration (pv_kernels.hip launch_synth_chain):
     // the window-sum denominators are then uploaded as reciprocals
     bool fast_chain() const { return use_chain && fast_capable(); }
@@ -530,11 +530,13 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
         auto lane_table = [&](const std::vector<cpx> &tw, DevBuf<float4> &dst) -> int {
             std::vector<cf> twc(tw.size());
             for (size_t i = 0; i < tw.size(); ++i) twc[i] = cf{tw[i].r, tw[i].i};
-            const int entries = d.fft.nc == 512    ? wf_lane_table_entries<WF<512>>()
+            const int entries = d.fft.nc == 256    ? wf_lane_table_entries<WF<256>>()
+                                : d.fft.nc == 512  ? wf_lane_table_entries<WF<512>>()
                                 : d.fft.nc == 1024 ? wf_lane_table_entries<WF<1024>>()
                                                    : wf_lane_table_entries<WF<2048>>();
             std::vector<cf> out(2 * (size_t)entries * 64);
-            if (d.fft.nc == 512) wf_build_lane_table<WF<512>>(twc.data(), out.data());
+            if (d.fft.nc == 256) wf_build_lane_table<WF<256>>(twc.data(), out.data());
+            else if (d.fft.nc == 512) wf_build_lane_table<WF<512>>(twc.data(), out.data());
             else if (d.fft.nc == 1024) wf_build_lane_table<WF<1024>>(twc.data(), out.data());
             else wf_build_lane_table<WF<2048>>(twc.data(), out.data());
             std::vector<float4> o4((size_t)entries * 64);
@@ -1340,7 +1342,7 @@ int pv_batch_create(const pv_config *cfg, int32_t nstreams, int64_t frames, int3
     // boundaries (each a drain and a refill of the chip): 52.0 vs 52.9 ms per bench step; 768 per row: no further gain.
     // Round 3: with PV_ARITH_FAST every wave-FFT configuration that has a free-form kernel takes the fused path at
     // any row count (Core::fast_capable), and the wide chunks with it (8-95 streams: +5...20 % over the tile path).
-    const bool fast_wave = g_arith == PV_ARITH_FAST && (cfg->fftsize > 512 && cfg->fftsize <= 4096);
+    const bool fast_wave = g_arith == PV_ARITH_FAST && (cfg->fftsize > 256 && cfg->fftsize <= 4096);
     const bool wide = rows >= 192 || fast_wave;
     int Tc = (wide ? 131072 : 65536) / (rows > 0 ? rows : 1);
     if (Tc < 16) Tc = 16;

@@ -612,11 +612,15 @@ template <typename K> static void allow_big_lds_dev(K kernel, unsigned long long
 }
 
 void launch_analyze(const AnalyzeArgs &a, hipStream_t st) {
-    if (a.tb.nc == 512) { // fft 1024: four passes (pv_wavefft.h WF<512>)
+    if (a.tb.nc == 512 || a.tb.nc == 256) { // fft 1024 / 512: four passes (pv_wavefft.h WF<512>, WF<256>)
         constexpr int WPB = 1;
         const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
-        hipLaunchKernelGGL((pv_analyze_wave_kernel<512, WPB>), dim3(grid), dim3(64 * WPB),
-                           WPB * WF<512>::LDS_CF * sizeof(cf) + 4 * PV_ATAN_BLOB_WORDS, st, a);
+        if (a.tb.nc == 512)
+            hipLaunchKernelGGL((pv_analyze_wave_kernel<512, WPB>), dim3(grid), dim3(64 * WPB),
+                               WPB * WF<512>::LDS_CF * sizeof(cf) + 4 * PV_ATAN_BLOB_WORDS, st, a);
+        else
+            hipLaunchKernelGGL((pv_analyze_wave_kernel<256, WPB>), dim3(grid), dim3(64 * WPB),
+                               WPB * WF<256>::LDS_CF * sizeof(cf) + 4 * PV_ATAN_BLOB_WORDS, st, a);
         return;
     }
     if (a.tb.nc == 1024 || a.tb.nc == 2048) {
@@ -1500,6 +1504,7 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
     // A lane owns runs of four consecutive bins, k = 4 (lane + 64 q) + c: one 16-byte load per run and plane
     // (the texture path is issue-bound), and the spectrum goes to LDS as two 16-byte writes per run.
     constexpr int QB = NC / 256; // runs per lane
+    constexpr int QH = (QB + 1) / 2; // magnitude runs fetched up front (the rest while those are being used)
     float4 base[QB], mreg[QB];
 #pragma unroll
     for (int q = 0; q < QB; ++q) base[q] = *reinterpret_cast<const float4 *>(psrc + 4 * (lane + 64 * q));
@@ -1509,7 +1514,7 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
     auto load_mags = [&]() { // issued once the peak list has left its registers (128-VGPR budget)
         if (plain) { // the first half now, the second half while the first is being used (see below)
 #pragma unroll
-            for (int q = 0; q < QB / 2; ++q) mreg[q] = *reinterpret_cast<const float4 *>(mag + 4 * (lane + 64 * q));
+            for (int q = 0; q < QH; ++q) mreg[q] = *reinterpret_cast<const float4 *>(mag + 4 * (lane + 64 * q));
             mnyq = mag[hs];
         } else if (a.do_freq_comp) { // freqCompSlice gathers across bins: the whole row, staged in LDS below
 #pragma unroll
@@ -1664,7 +1669,7 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
         if (kFast || __builtin_amdgcn_ballot_w64(!(pmax <= PV_SINCOS_MAX_ARG)) == 0) {
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
-                if (q < QB / 2) mreg[q + QB / 2] = *reinterpret_cast<const float4 *>(mag + 4 * (lane + 64 * (q + QB / 2)));
+                if (q + QH < QB) mreg[q + QH] = *reinterpret_cast<const float4 *>(mag + 4 * (lane + 64 * (q + QH)));
                 xs[q][0] = to_cartesian_small(mreg[q].x, base[q].x);
                 xs[q][1] = to_cartesian_small(mreg[q].y, base[q].y);
                 xs[q][2] = to_cartesian_small(mreg[q].z, base[q].z);
@@ -1674,7 +1679,7 @@ __device__ __forceinline__ void synth_wave_role(const SynthArgs &a_in, const int
         } else {
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
-                if (q < QB / 2) mreg[q + QB / 2] = *reinterpret_cast<const float4 *>(mag + 4 * (lane + 64 * (q + QB / 2)));
+                if (q + QH < QB) mreg[q + QH] = *reinterpret_cast<const float4 *>(mag + 4 * (lane + 64 * (q + QH)));
                 xs[q][0] = to_cartesian(mreg[q].x, base[q].x);
                 xs[q][1] = to_cartesian(mreg[q].y, base[q].y);
                 xs[q][2] = to_cartesian(mreg[q].z, base[q].z);
@@ -1901,14 +1906,20 @@ static bool synth_generic_only() {
 }
 
 void launch_synth(const SynthArgs &a, hipStream_t st) {
-    if (a.tb.nc == 512) { // fft 1024 (round 3): the phase-locked plain specialisation, else the all-modes kernel
+    if (a.tb.nc == 512 || a.tb.nc == 256) { // fft 1024 / 512 (round 3): the phase-locked plain specialisation, else the all-modes kernel
         constexpr int WPB = 1;
         const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
-        const size_t lds = WPB * WF<512>::LDS_CF * sizeof(cf);
         const bool plain = !a.do_freq_comp && a.voc_band_len < 0 && !a.robotic && !a.passthru && !a.whisper &&
                            !synth_generic_only();
-        if (plain && a.coremode == 1) hipLaunchKernelGGL((pv_synth_wave_kernel<512, WPB, 1>), dim3(grid), dim3(64 * WPB), lds, st, a);
-        else hipLaunchKernelGGL((pv_synth_wave_kernel<512, WPB>), dim3(grid), dim3(64 * WPB), lds, st, a);
+        if (a.tb.nc == 512) {
+            const size_t lds = WPB * WF<512>::LDS_CF * sizeof(cf);
+            if (plain && a.coremode == 1) hipLaunchKernelGGL((pv_synth_wave_kernel<512, WPB, 1>), dim3(grid), dim3(64 * WPB), lds, st, a);
+            else hipLaunchKernelGGL((pv_synth_wave_kernel<512, WPB>), dim3(grid), dim3(64 * WPB), lds, st, a);
+        } else {
+            const size_t lds = WPB * WF<256>::LDS_CF * sizeof(cf);
+            if (plain && a.coremode == 1) hipLaunchKernelGGL((pv_synth_wave_kernel<256, WPB, 1>), dim3(grid), dim3(64 * WPB), lds, st, a);
+            else hipLaunchKernelGGL((pv_synth_wave_kernel<256, WPB>), dim3(grid), dim3(64 * WPB), lds, st, a);
+        }
         return;
     }
     if (a.tb.nc == 1024 || a.tb.nc == 2048) {
@@ -2918,7 +2929,8 @@ template <int kRes> __global__ __launch_bounds__(1024) void pv_frames_chain_kern
 }
 
 size_t chain_lds_bytes(const ChainArgs &a, int nc_wave) {
-    const size_t per_wave = nc_wave == 512    ? WF<512>::LDS_CF * sizeof(cf)
+    const size_t per_wave = nc_wave == 256    ? WF<256>::LDS_CF * sizeof(cf)
+                            : nc_wave == 512  ? WF<512>::LDS_CF * sizeof(cf)
                             : nc_wave == 1024 ? WF<1024>::LDS_CF * sizeof(cf)
                             : nc_wave == 2048 ? WF<2048>::LDS_CF * sizeof(cf) : 0;
     return (size_t)a.waves * per_wave + chain_shared_bytes(a);
@@ -2961,7 +2973,7 @@ bool synth_chain_has_fast(const SynthArgs &s) {
     const bool fc_locked = s.do_freq_comp && s.voc_band_len < 0 && !s.robotic && !s.passthru && !s.whisper &&
                            !synth_generic_only() && s.coremode == 1;
     return (s.tb.nc == 1024 && (plain || fc_locked)) || (s.tb.nc == 2048 && plain) ||
-           (s.tb.nc == 512 && plain);
+           ((s.tb.nc == 512 || s.tb.nc == 256) && plain);
 }
 
 void launch_synth_chain(const SynthArgs &s, const ChainArgs &c, hipStream_t st) {
@@ -2969,7 +2981,12 @@ void launch_synth_chain(const SynthArgs &s, const ChainArgs &c, hipStream_t st) 
                        !synth_generic_only() && s.coremode >= 0 && s.coremode <= 2;
     const bool fc_locked = s.do_freq_comp && s.voc_band_len < 0 && !s.robotic && !s.passthru && !s.whisper &&
                            !synth_generic_only() && s.coremode == 1;
-    if (s.tb.nc == 512) { // fft 1024: the plain specialisations (sixteen waves, as the engine sizes the launch), else all modes
+    if (s.tb.nc == 256) { // fft 512
+        if (plain && s.coremode == 1) launch_synth_chain_res<256, 1>(s, c, st);
+        else if (plain && s.coremode == 0) launch_synth_chain_res<256, 0>(s, c, st);
+        else if (plain) launch_synth_chain_res<256, 2>(s, c, st);
+        else launch_synth_chain_res<256, -1>(s, c, st);
+    } else if (s.tb.nc == 512) { // fft 1024: the plain specialisations (sixteen waves, as the engine sizes the launch), else all modes
         if (plain && s.coremode == 1) launch_synth_chain_res<512, 1>(s, c, st);
         else if (plain && s.coremode == 0) launch_synth_chain_res<512, 0>(s, c, st);
         else if (plain) launch_synth_chain_res<512, 2>(s, c, st);
@@ -3305,7 +3322,8 @@ bool stream_kernel_supported(const StreamArgs &s) {
 // the kernels that contain it have no static LDS (their dynamic LDS then starts at 0).  The engine asks once per
 // device, at creation.
 bool lds_starts_at_zero() {
-    const void *ks[] = {reinterpret_cast<const void *>(pv_analyze_wave_kernel<512, 1>),
+    const void *ks[] = {reinterpret_cast<const void *>(pv_analyze_wave_kernel<256, 1>),
+                        reinterpret_cast<const void *>(pv_analyze_wave_kernel<512, 1>),
                         reinterpret_cast<const void *>(pv_analyze_wave_kernel<1024, 1>),
                         reinterpret_cast<const void *>(pv_analyze_wave_kernel<2048, 1>),
                         reinterpret_cast<const void *>(pv_stream_kernel<1024>),

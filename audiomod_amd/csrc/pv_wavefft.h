@@ -59,6 +59,20 @@ template <> struct WF<512> {
     static constexpr int LDS_CF = 512 + 32 + 8;
 };
 
+// ... and 256 complex points (fft 512), four elements per lane: kissfft's 4 4 4 4, one stage per pass.
+template <> struct WF<256> {
+    static constexpr int N_C = 256, LOG = 8, R = 4, RB = 2, NSTAGE = 4, NPASS = 4;
+    static constexpr int st_radix[6] = {4, 4, 4, 4, 0, 0};
+    static constexpr int st_bit[6] = {0, 2, 4, 6, 0, 0};
+    static constexpr int st_pass[6] = {0, 1, 2, 3, 0, 0};
+    static constexpr int regpos[4][5] = {{0, 1, 0, 0, 0}, {2, 3, 0, 0, 0}, {4, 5, 0, 0, 0}, {6, 7, 0, 0, 0}};
+    static constexpr int lanepos[4][6] = {{2, 3, 4, 5, 6, 7}, {0, 1, 4, 5, 6, 7}, {0, 1, 2, 3, 6, 7}, {0, 1, 2, 3, 4, 5}};
+    // e = d0 + 4 d1 + 16 d2 + 64 d3  <-  src = d3 + 4 d2 + 16 d1 + 64 d0
+    static constexpr int srcbit[11] = {6, 7, 4, 5, 2, 3, 0, 1, 0, 0, 0};
+    static PV_HD int pad(int e) { return e + (e >> 4); }
+    static constexpr int LDS_CF = 256 + 16 + 8;
+};
+
 template <> struct WF<1024> {
     static constexpr int N_C = 1024, LOG = 10, R = 16, RB = 4, NSTAGE = 5, NPASS = 3;
     static constexpr int st_radix[6] = {4, 4, 4, 4, 4, 0};
@@ -168,12 +182,12 @@ template <class W, int S, bool INV> PV_HD void wf_stage(cf (&v)[W::R], int lp, c
 }
 
 template <class W, int P, bool INV> PV_HD void wf_run_pass_stages(cf (&v)[W::R], int lp, const cf *__restrict__ tw) {
-    if (W::NSTAGE > 0 && W::st_pass[0] == P) wf_stage<W, 0, INV>(v, lp, tw);
-    if (W::NSTAGE > 1 && W::st_pass[1] == P) wf_stage<W, 1, INV>(v, lp, tw);
-    if (W::NSTAGE > 2 && W::st_pass[2] == P) wf_stage<W, 2, INV>(v, lp, tw);
-    if (W::NSTAGE > 3 && W::st_pass[3] == P) wf_stage<W, 3, INV>(v, lp, tw);
-    if (W::NSTAGE > 4 && W::st_pass[4] == P) wf_stage<W, 4, INV>(v, lp, tw);
-    if (W::NSTAGE > 5 && W::st_pass[5] == P) wf_stage<W, (W::NSTAGE > 5 ? 5 : 0), INV>(v, lp, tw);
+    if constexpr (W::NSTAGE > 0 && W::st_pass[0] == P) wf_stage<W, 0, INV>(v, lp, tw);
+    if constexpr (W::NSTAGE > 1 && W::st_pass[1] == P) wf_stage<W, 1, INV>(v, lp, tw);
+    if constexpr (W::NSTAGE > 2 && W::st_pass[2] == P) wf_stage<W, 2, INV>(v, lp, tw);
+    if constexpr (W::NSTAGE > 3 && W::st_pass[3] == P) wf_stage<W, 3, INV>(v, lp, tw);
+    if constexpr (W::NSTAGE > 4 && W::st_pass[4] == P) wf_stage<W, 4, INV>(v, lp, tw);
+    if constexpr (W::NSTAGE > 5 && W::st_pass[5] == P) wf_stage<W, 5, INV>(v, lp, tw);
 }
 
 // ---- the same stages with their twiddles fetched ahead of time ---------------------------------

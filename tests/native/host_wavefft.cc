@@ -201,6 +201,8 @@ template <int NC, bool INV> static int check(unsigned seed) {
 
 int main() {
     int rc = 0;
+    rc |= check<256, false>(7);
+    rc |= check<256, true>(8);
     rc |= check<512, false>(5);
     rc |= check<512, true>(6);
     rc |= check<1024, false>(1);

@@ -799,15 +799,16 @@ FFT1024 = [dict(semitones=4.0), dict(semitones=2.0, coremode=0), dict(semitones=
 
 
 @pytest.mark.parametrize("arith", ["fast", "exact"])
+@pytest.mark.parametrize("fftsize", [512, 1024])
 @pytest.mark.parametrize("kw", FFT1024, ids=[str(i) for i in range(len(FFT1024))])
-def test_fft1024_runs_through_the_wave_per_frame_kernels(kw, arith):
-    """Round 3: 1024-point frames (512 complex points, kissfft stages 2 4 4 4 4) have a wave-per-frame transform too --
-    four passes of eight elements per lane (pv_wavefft.h WF<512>; the core is checked bit for bit on the host,
-    tests/native/host_wavefft.cc) -- and with it the fused overlap-add path and, for the plain modes, the free-form
-    kernels.  Streaming and batch API against the oracle under both arithmetic settings; ROBOTIC bit for bit; the batch
-    equal to the stream bit for bit."""
+def test_fft512_and_1024_run_through_the_wave_per_frame_kernels(kw, fftsize, arith):
+    """Round 3: 1024- and 512-point frames (512 / 256 complex points, kissfft stages 2 4 4 4 4 / 4 4 4 4) have a
+    wave-per-frame transform too -- four passes of eight / four elements per lane (pv_wavefft.h WF<512>, WF<256>; the
+    core is checked bit for bit on the host, tests/native/host_wavefft.cc) -- and with it the fused overlap-add path
+    and, for the plain modes, the free-form kernels.  Streaming and batch API against the oracle under both arithmetic
+    settings; ROBOTIC bit for bit; the batch equal to the stream bit for bit."""
     import torch
-    kw = dict(kw, fftsize=1024)
+    kw = dict(kw, fftsize=fftsize)
     flush = kw.pop("flush", True)
     x = signals.voice(30000, 2, seed=77)
     prev = E.get_arithmetic()

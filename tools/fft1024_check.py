@@ -1,5 +1,5 @@
-"""fft 1024 through the wave-per-frame kernels (round 3, four-pass WF<512>): every mode, streaming and batch API, both
-arithmetic settings, against the oracle.  usage (GPU box): python tools/fft1024_check.py"""
+"""fft 1024 / 512 through the wave-per-frame kernels (round 3, four-pass WF<512> / WF<256>): every mode, streaming and
+batch API, both arithmetic settings, against the oracle.  usage (GPU box): python tools/fft1024_check.py [fftsize=1024]"""
 import os
 import sys
 
@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 from audiomod_amd import engine as E, signals  # noqa: E402
 from oracle import oracle_py as O  # noqa: E402
 
+FFT = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 x = signals.voice(30000, 2, seed=77)
 cases = [dict(semitones=4.0), dict(semitones=2.0, coremode=0), dict(semitones=2.0, coremode=2), dict(semitones=-7.0),
          dict(mode="time_stretch", time_ratio=1.5, flush=False), dict(mode="formant_pitchshift", semitones=5.0),
@@ -20,7 +21,7 @@ bad = 0
 for arith in (E.ARITH_FAST, E.ARITH_EXACT):
     E.set_arithmetic(arith)
     for kw in cases:
-        kw = dict(kw, fftsize=1024)
+        kw = dict(kw, fftsize=FFT)
         flush = kw.pop("flush", True)
         want, wc, _ = O.run_offline(x, flush=flush, **kw)
         got, gc = E.run_offline(x, flush=flush, **kw)
