@@ -36,7 +36,7 @@ extern "C" {
 /* Extension, not a value of the reference's enum: pitch shift whose formants are restored by the reference's
  * cepstral formant shift (formantShiftSlice, phasevocoderprocess.cc:925-999, with env_comp = the pitch scale) --
  * code the reference carries but never calls (its call in formantPreserveSlice is commented out, :838).
- * fftsize 2048 or 4096 only. */
+ * Any fftsize from 128 up (its lifter keeps 60 quefrencies). */
 #define PV_MODE_FORMANT_CEPSTRAL 8
 #define PV_CORE_NORMAL_PV 0
 #define PV_CORE_PHASE_LOCKED 1
@@ -87,8 +87,8 @@ typedef struct pv_info {
  *   PV_ARITH_EXACT  resynthesis, overlap-add, normalisation and resampling also in the reference's operation order
  *                   (bit-identical to the reference except for the sine / cosine of the resynthesis; ROBOTIC mode
  *                   bit-identical end to end);
- *   PV_ARITH_FAST   where a free-form kernel exists -- the plain pitch-shift / stretch modes in every core mode and
- *                   the formant / gender modes, at fft 2048 and 4096 -- resynthesis, normalisation and resampling may
+ *   PV_ARITH_FAST   where a free-form kernel exists -- the plain pitch-shift / stretch modes in every core mode at fft
+ *                   512 ... 4096, the formant / gender modes at fft 2048 -- resynthesis, normalisation and resampling may
  *                   fuse multiply-adds, regroup sums, skip phase wraps and use the hardware's sine / cosine
  *                   (measured: 1e-8 ... 5e-8 RMS against the reference).  Such a configuration then always takes the
  *                   fused overlap-add path, in the single-stream engine and in batches of any size alike, so every
@@ -184,7 +184,7 @@ int pv_batch_run(pv_batch *b, const float *d_in, float *d_out, void *hip_stream)
 #define PV_K_SYNTH 4        /* phase application + freqComp + inverse real FFT + window */
 #define PV_K_OLA_RESAMPLE 5 /* overlap-add + normalise + resample */
 #define PV_K_CEPSTRAL 6     /* PV_MODE_FORMANT_CEPSTRAL: cepstral envelope shift of the magnitudes */
-#define PV_K_SYNTH_OLA 7    /* PV_K_SYNTH and PV_K_OLA_RESAMPLE fused: synthesis frames overlap-added in LDS (fft 2048 /
+#define PV_K_SYNTH_OLA 7    /* PV_K_SYNTH and PV_K_OLA_RESAMPLE fused: synthesis frames overlap-added in LDS (fft 512 ...
                                4096; the default -- AUDIOMOD_PV_FUSED=0 brings the two separate kernels back) */
 int pv_batch_enable_timing(pv_batch *b, int on);
 int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launches[PV_NUM_KERNELS]);
