@@ -475,7 +475,11 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
             const char *g = getenv("AUDIOMOD_PV_SYNTH_GENERIC"); // (tests: every mode through the all-modes variant)
             const bool plain = !d.do_freq_comp && !d.vocoder && !d.robotic && !d.constant && !d.whisper &&
                                !(g && atoi(g) != 0);
-            if (!plain && wmax > 12) wmax = 12;
+            // (round 3: the FREE-FORM formant / gender kernel fits 128 registers, sixteen waves: pv_kernels.hip
+            // chain_kernel_max_threads)
+            const bool fc_fast = d.do_freq_comp && !d.vocoder && !d.robotic && !d.constant && !d.whisper && !(g && atoi(g) != 0) &&
+                                 d.cfg.coremode == 1 && d.fft.nc == 1024 && fast_capable();
+            if (!plain && !fc_fast && wmax > 12) wmax = 12;
         }
         if (const char *e = getenv("AUDIOMOD_PV_CHAIN_WAVES")) { // tuning knob: upper bound of waves per workgroup
             const int v = atoi(e);

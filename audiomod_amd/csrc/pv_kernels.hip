@@ -2835,8 +2835,14 @@ __device__ __forceinline__ void chain_slice_tail(const ChainArgs &c_in, const Ch
 
 // (the all-modes variant -- frequency compression, vocoder, ... -- needs ~150 VGPRs where the plain ones fit 128:
 // compiled for twelve waves per workgroup, three per SIMD, instead of spilling)
+// Threads per workgroup each variant is compiled for: sixteen waves (128 registers) for the specialisations, twelve for
+// the all-modes kernel and the exact formant / gender one (~150 registers); the free-form formant / gender kernel fits
+// 128 (round 3).  4096-point frames: eight waves (LDS).  Core::init sizes the launch by the same rule.
+constexpr int chain_kernel_max_threads(int NC, int kPlainCore, bool kFast) {
+    return NC <= 1024 ? ((kPlainCore < 0 || (kPlainCore == 3 && !kFast)) ? 768 : 1024) : 512;
+}
 template <int NC, int kPlainCore, int kRes, bool kFast = false>
-__global__ __launch_bounds__(NC <= 1024 ? ((kPlainCore < 0 || kPlainCore == 3) ? 768 : 1024) : 512) void pv_synth_chain_kernel(
+__global__ __launch_bounds__(chain_kernel_max_threads(NC, kPlainCore, kFast)) void pv_synth_chain_kernel(
     const SynthArgs s, const ChainArgs c) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
@@ -2938,7 +2944,8 @@ size_t chain_lds_bytes(const ChainArgs &a, int nc_wave) {
 
 template <int NC, int kPlainCore> static void launch_synth_chain_res(const SynthArgs &s, const ChainArgs &c, hipStream_t st) {
     const size_t lds = chain_lds_bytes(c, NC);
-    constexpr int kMaxThreads = NC <= 1024 ? ((kPlainCore < 0 || kPlainCore == 3) ? 768 : 1024) : 512; // the kernel's launch bounds
+    const bool use_fast = kPlainCore >= 0 && c.fast;
+    const int kMaxThreads = use_fast ? chain_kernel_max_threads(NC, kPlainCore, true) : chain_kernel_max_threads(NC, kPlainCore, false);
     if (64 * c.waves > kMaxThreads) { // (never: Core::init sizes chain_waves by the same rule; a launch beyond the bounds faults)
         fprintf(stderr, "audiomod_pv: fused kernel launch of %d waves exceeds its bounds (%d threads): not launched\n", c.waves, kMaxThreads);
         return;
