@@ -206,3 +206,23 @@ def test_planner_window_is_the_oracles(N):
     want, area = np.zeros(N, np.float32), np.zeros(1, np.float32)
     O.lib().pvo_hann(N, want.ctypes.data, area.ctypes.data)
     assert np.array_equal(win.view(np.uint32), want.view(np.uint32))
+
+
+def test_arithmetic_setting_round_trip_and_environment_default():
+    """pv_set_arithmetic / pv_get_arithmetic (include/audiomod_pv.h): process-wide, PV_ARITH_FAST by default,
+    PV_ARITH_EXACT when the environment says AUDIOMOD_PV_EXACT=1 at load time; anything else is refused.  No GPU needed."""
+    import subprocess
+    import sys
+    L = E.lib()
+    prev = L.pv_get_arithmetic()
+    try:
+        assert L.pv_set_arithmetic(E.ARITH_EXACT) == 0 and L.pv_get_arithmetic() == E.ARITH_EXACT
+        assert L.pv_set_arithmetic(E.ARITH_FAST) == 0 and L.pv_get_arithmetic() == E.ARITH_FAST
+        assert L.pv_set_arithmetic(7) != 0 and L.pv_get_arithmetic() == E.ARITH_FAST
+        assert E.set_arithmetic(E.ARITH_EXACT) == E.ARITH_FAST and E.get_arithmetic() == E.ARITH_EXACT
+    finally:
+        L.pv_set_arithmetic(prev)
+    code = "import sys; sys.path.insert(0, %r); from audiomod_amd import engine as E; print(E.get_arithmetic())" % ROOT
+    for env, want in (({"AUDIOMOD_PV_EXACT": "1"}, "1"), ({"AUDIOMOD_PV_EXACT": "0"}, "0")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == want, r.stdout + r.stderr
