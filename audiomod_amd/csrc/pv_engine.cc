@@ -306,6 +306,7 @@ struct Core {
     static constexpr int kChainMinRows = 192;
     bool fast_arith = false;  // set before init() by the batch engine (audiomod_pv.h PV_ARITH_FAST); only the fused
                               // wave-FFT path has the fast kernels, everything else computes exactly either way
+    bool fuse_phase = false;  // single-stream engine: match kernel and rotation chain in one launch (set by pv_create)
     bool ahead = false;       // three-stage order with the analysis one chunk further ahead (pv_batch_run): planes hold three chunks
     bool three_stage = false; // pipelined batch path: resampling of chunk i-2 between the front of i and the fused kernel of i-1
     int chain_AR = 0, chain_smask = 0, chain_waves = 0;
@@ -890,9 +891,10 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
         ma.npk = npk.p;
         ma.recs = recs.p;
         ma.modes = modes.p;
+        const bool phase_fused = fuse_phase && part == 0 && !single_launch && !ev; // (filled in below: needs qa)
         if (front && !only_chain) rec(2 * PV_K_MATCH);
         if (single_launch) fused.ma = ma;
-        else if (front && !only_chain) launch_match(ma, st); HIPV(hipGetLastError());
+        else if (front && !only_chain && !phase_fused) launch_match(ma, st); HIPV(hipGetLastError());
         if (front && !only_chain) rec(2 * PV_K_MATCH + 1);
         SeqArgs qa{};
         qa.N = d.N;
@@ -931,7 +933,13 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
             qa.narrow = narrow;
         }
         if (single_launch) fused.qa = qa;
-        else side_stream(PV_K_SEQ, [&](hipStream_t s) { launch_seq(qa, s); HIPV(hipGetLastError()); });
+        else if (phase_fused) {
+            if (!launch_phase(ma, qa, st)) { // (does not fit one workgroup's LDS: the two kernels after all)
+                launch_match(ma, st); HIPV(hipGetLastError());
+                launch_seq(qa, st);
+            }
+            HIPV(hipGetLastError());
+        } else side_stream(PV_K_SEQ, [&](hipStream_t s) { launch_seq(qa, s); HIPV(hipGetLastError()); });
     } else if (cm == 0) {
         PropArgs pa{};
         pa.N = d.N;
@@ -1236,6 +1244,15 @@ struct pv_engine {
     DevBuf<char> d_desc;
     PinBuf<float> h_in, h_out;
     PinBuf<char> h_desc;
+    // Round 3: a call's kernels write their output straight into page-locked host memory (h_out is mapped into the
+    // device's address space: out_dev) and the stream then writes a sequence number into h_flag, which pv_feed spins
+    // on -- no device-to-host copy and no hipStreamSynchronize per call (AUDIOMOD_PV_STREAM_SYNC=1: the copy + the
+    // synchronisation, as before).
+    PinBuf<uint32_t> h_flag;
+    float *out_dev = nullptr;     // device-side address of h_out
+    uint32_t *flag_dev = nullptr; // ... of h_flag
+    uint32_t flag_seq = 0;
+    bool direct_out = false;
     int out_cap = 0; // per-row capacity of d_out / h_out
     std::vector<std::vector<float>> outq; // per channel FIFO
     size_t outq_head = 0;
@@ -1704,6 +1721,8 @@ int pv_batch_kernel_times(pv_batch *b, double ms[PV_NUM_KERNELS], int64_t launch
 // ---------------------------------------------------------------- streaming
 static constexpr int kStreamChunk = 16; // slices per launch group in streaming mode
 
+static int map_out(pv_engine *e);
+
 int pv_create(const pv_config *cfg, int device, pv_engine **out) {
     g_last_error.clear();
     plan_reason_clear();
@@ -1712,6 +1731,10 @@ int pv_create(const pv_config *cfg, int device, pv_engine **out) {
     std::unique_ptr<pv_engine> e(new pv_engine());
     e->core.chain_required = true;
     e->core.fast_arith = g_arith == PV_ARITH_FAST; // (same kernels as the batch engine: see Core::fast_capable)
+    {
+        const char *ef = getenv("AUDIOMOD_PV_STREAM_FUSE_PHASE"); // =0: match kernel and rotation chain as two launches
+        e->core.fuse_phase = !(ef && atoi(ef) == 0);
+    }
     int st = e->core.init(*cfg, device, 1, kStreamChunk);
     if (st != PV_OK) return st;
     Core &c = e->core;
@@ -1731,6 +1754,13 @@ int pv_create(const pv_config *cfg, int device, pv_engine **out) {
     e->out_cap = (int)(kStreamChunk * per_slice) + 64;
     if ((st = e->d_out.alloc((size_t)c.C * e->out_cap)) != PV_OK) return st;
     if ((st = e->h_out.alloc((size_t)c.C * e->out_cap)) != PV_OK) return st;
+    if ((st = e->h_flag.alloc(16)) != PV_OK) return st;
+    e->h_flag.p[0] = 0;
+    {
+        const char *es = getenv("AUDIOMOD_PV_STREAM_SYNC");
+        e->direct_out = !(es && atoi(es) != 0);
+    }
+    if ((st = map_out(e.get())) != PV_OK) return st;
     const size_t desc_bytes = 256 * 1024; // grows on demand (ensure_desc)
     if ((st = e->d_desc.alloc(desc_bytes)) != PV_OK) return st;
     if ((st = e->h_desc.alloc(desc_bytes)) != PV_OK) return st;
@@ -1794,6 +1824,15 @@ static int ensure_desc(pv_engine *e, size_t bytes) {
     if (st != PV_OK) return st;
     return e->d_desc.alloc(cap);
 }
+static int map_out(pv_engine *e) { // (after h_out / h_flag were allocated)
+    if (!e->direct_out) return PV_OK;
+    void *p = nullptr;
+    HIPC(hipHostGetDevicePointer(&p, e->h_out.p, 0));
+    e->out_dev = static_cast<float *>(p);
+    HIPC(hipHostGetDevicePointer(&p, e->h_flag.p, 0));
+    e->flag_dev = static_cast<uint32_t *>(p);
+    return PV_OK;
+}
 static int ensure_out(pv_engine *e, int64_t cnt) {
     if (cnt <= e->out_cap) return PV_OK;
     int cap = e->out_cap;
@@ -1803,7 +1842,7 @@ static int ensure_out(pv_engine *e, int64_t cnt) {
     if (st != PV_OK) return st;
     if ((st = e->h_out.alloc((size_t)e->core.C * cap)) != PV_OK) return st;
     e->out_cap = cap;
-    return PV_OK;
+    return map_out(e);
 }
 
 int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
@@ -1944,22 +1983,51 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
             cl.res_tiles = reinterpret_cast<const ResTile *>(e->d_desc.p + o_d);
             cl.res_otab = reinterpret_cast<const uint2 *>(e->d_desc.p + o_e);
             cl.res_ntiles = (int)res_tiles.size();
-            cl.out = e->d_out.p;
+            cl.out = e->direct_out ? e->out_dev : e->d_out.p;
         }
         c.launch_chunk(ia, ta, Tn, reinterpret_cast<const int32_t *>(e->d_desc.p + o_pinc),
                        reinterpret_cast<const OlaTile *>(e->d_desc.p + o_b), (int)tiles.size(),
                        reinterpret_cast<const int64_t *>(e->d_desc.p + o_a),
                        reinterpret_cast<const float *>(e->d_desc.p + o_c), e->d_whisper.p,
-                       c.d.vocoder ? &car : nullptr, e->d_out.p, e->out_cap, ka, e->stream, nullptr, 0, nullptr, nullptr,
+                       c.d.vocoder ? &car : nullptr, e->direct_out ? e->out_dev : e->d_out.p, e->out_cap, ka, e->stream,
+                       nullptr, 0, nullptr, nullptr,
                        nullptr, c.can_single_launch(), c.use_chain ? &cl : nullptr);
         if ((st = c.take_launch_error()) != PV_OK) return fail(st);
         const int64_t cnt = kb - ka;
         hipError_t he = hipSuccess;
-        if (cnt > 0)
-            he = hipMemcpy2DAsync(e->h_out.p, (size_t)e->out_cap * sizeof(float), e->d_out.p,
-                                  (size_t)e->out_cap * sizeof(float), (size_t)cnt * sizeof(float), (size_t)c.C,
-                                  hipMemcpyDeviceToHost, e->stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        const bool last_group = tb == t_new1;
+        if (e->direct_out) {
+            // what the call leaves unconsumed goes to the device ring behind the last group's kernels, in front of
+            // the flag: one wait per call
+            if (last_group && (st = upload_until(e, in, call_base, e->fed)) != PV_OK) return fail(st);
+            const uint32_t seq = ++e->flag_seq;
+            he = hipStreamWriteValue32(e->stream, e->flag_dev, seq, 0);
+            if (he == hipSuccess) {
+                // spin on the host copy of the flag; look at the stream every ~4096 polls so that a failed launch ends the
+                // wait instead of hanging it
+                volatile uint32_t *fl = e->h_flag.p;
+                uint32_t spins = 0;
+                while (__atomic_load_n(fl, __ATOMIC_ACQUIRE) != seq) {
+                    if ((++spins & 0xfffu) == 0) {
+                        const hipError_t q = hipStreamQuery(e->stream);
+                        if (q != hipSuccess && q != hipErrorNotReady) {
+                            he = q;
+                            break;
+                        }
+                        if (q == hipSuccess && __atomic_load_n(fl, __ATOMIC_ACQUIRE) != seq && spins > (1u << 26)) {
+                            he = hipErrorUnknown; // the stream is idle and the flag never arrived
+                            break;
+                        }
+                    }
+                }
+            }
+        } else {
+            if (cnt > 0)
+                he = hipMemcpy2DAsync(e->h_out.p, (size_t)e->out_cap * sizeof(float), e->d_out.p,
+                                      (size_t)e->out_cap * sizeof(float), (size_t)cnt * sizeof(float), (size_t)c.C,
+                                      hipMemcpyDeviceToHost, e->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        }
         if (he == hipSuccess) he = hipGetLastError();
         if (he != hipSuccess) return fail(hip_fail(he, "streaming launch group", __LINE__));
         for (int ch = 0; ch < c.C && cnt > 0; ++ch) {
@@ -1974,8 +2042,10 @@ int pv_feed(pv_engine *e, const float *const *in, int32_t n) {
         }
     }
     // everything fed stays needed by later slices (at most 2N unconsumed): park it in the device ring
-    if ((st = upload_until(e, in, call_base, e->fed)) != PV_OK) return fail(st);
-    if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "stream sync", __LINE__));
+    if (e->uploaded < e->fed || !e->direct_out) { // (direct output: the last group's flag already covered the upload)
+        if ((st = upload_until(e, in, call_base, e->fed)) != PV_OK) return fail(st);
+        if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "stream sync", __LINE__));
+    }
     return PV_OK;
 }
 

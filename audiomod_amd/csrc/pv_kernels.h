@@ -266,6 +266,7 @@ struct ResArgs {
     int fast; // arithmetic free within the 1e-4 RMS contract (pv_resample_fast_kernel) instead of the reference's order
 };
 void launch_resample(const ResArgs &a, hipStream_t st);
+bool launch_phase(const MatchArgs &m, const SeqArgs &a, hipStream_t st); // single-stream engine: match + chain in one launch
 size_t chain_lds_bytes(const ChainArgs &a, int nc_wave /* 0: frames from HBM */);
 void launch_synth_chain(const SynthArgs &s, const ChainArgs &c, hipStream_t st); // nc 1024 / 2048
 void launch_frames_chain(const ChainArgs &c, hipStream_t st);                    // any size, frames from HBM

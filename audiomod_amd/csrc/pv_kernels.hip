@@ -1192,6 +1192,23 @@ template <int kK> __global__ __launch_bounds__(1024) void pv_seq_kernel(const Se
     seq_role<kK>(a, blockIdx.x, smem_raw);
 }
 
+// Single-stream engine: match and rotation chain in ONE launch (round 3).  A 480-frame call is two or three steps per
+// row: far too little for the two kernels to need separate grids, and every launch costs the host ~7 us of the call's
+// ~70.  One workgroup per row: its waves match the row's steps (a step's match depends on analysis results only, of
+// this row and its neighbour channel -- nothing another workgroup of this launch writes), then, behind a device-scope
+// fence and a barrier, the same workgroup walks the chain.  Same device functions, same results.
+template <int D> __global__ __launch_bounds__(1024) void pv_phase_kernel(const MatchArgs m, const SeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    for (int tl = wave; tl < m.Tn; tl += nw)
+        match_wave_role(m, blockIdx.x, tl, smem_raw + (size_t)wave * match_wave_lds(m.hs, m.PKP));
+    __threadfence(); // the records go through global memory: the chain's loads must see them
+    __syncthreads();
+    if (a.high_prio) __builtin_amdgcn_s_setprio(3);
+    seq_role_ring<D>(a, blockIdx.x, smem_raw);
+}
+
 int seq_threads(int PKP) {
     int nt = (PKP + 63) & ~63;
     if (nt > 1024) nt = 1024;
@@ -1239,6 +1256,20 @@ void launch_seq(const SeqArgs &a, hipStream_t st) {
     }
     allow_big_lds_dev(pv_seq_kernel<1>, big1);
     hipLaunchKernelGGL(pv_seq_kernel<1>, dim3(a.rows), dim3(nt), lds, st, a);
+}
+
+// (true when the fused kernel was launched; false: the caller launches the two kernels)
+bool launch_phase(const MatchArgs &m, const SeqArgs &a, hipStream_t st) {
+    constexpr int D = 8;
+    const int nt = seq_threads(a.PKP);
+    const size_t seq_l = ((seq_lds_bytes(a) + 15) & ~(size_t)15) + (size_t)D * nt * sizeof(PeakRec);
+    const size_t match_l = (size_t)(nt / 64) * match_wave_lds(m.hs, m.PKP);
+    const size_t lds = seq_l > match_l ? seq_l : match_l;
+    if (a.PKP > nt || lds > 160 * 1024 - 512 || a.narrow) return false;
+    static unsigned long long big = 0;
+    allow_big_lds_dev(pv_phase_kernel<D>, big);
+    hipLaunchKernelGGL(pv_phase_kernel<D>, dim3(a.rows), dim3(nt), lds, st, m, a);
+    return true;
 }
 
 // --------------------------------------------------------------------------------------------
