@@ -307,6 +307,7 @@ struct Core {
     bool fast_arith = false;  // set before init() by the batch engine (audiomod_pv.h PV_ARITH_FAST); only the fused
                               // wave-FFT path has the fast kernels, everything else computes exactly either way
     bool fuse_phase = false;  // single-stream engine: match kernel and rotation chain in one launch (set by pv_create)
+    bool split_analysis = false; // 4096-point frames: the analysis kernel with a frame on two waves (pv_analyze_split_kernel)
     bool ahead = false;       // three-stage order with the analysis one chunk further ahead (pv_batch_run): planes hold three chunks
     bool three_stage = false; // pipelined batch path: resampling of chunk i-2 between the front of i and the fused kernel of i-1
     int chain_AR = 0, chain_smask = 0, chain_waves = 0;
@@ -548,7 +549,22 @@ int Core::init(const pv_config &cfg, int dev, int nstreams, int chunk_slices) {
             for (size_t i = 0; i < o4.size(); ++i) o4[i] = make_float4(out[2 * i].x, out[2 * i].y, out[2 * i + 1].x, out[2 * i + 1].y);
             return dst.upload(o4);
         };
-        if ((st = lane_table(d.fft.tw_fwd, twl_fwd)) != PV_OK) return st;
+        {
+            // AUDIOMOD_PV_SPLIT_ANALYSIS=0: the one-wave kernel (also what the opt-in one-workgroup streaming kernel calls)
+            const char *es = getenv("AUDIOMOD_PV_SPLIT_ANALYSIS");
+            const char *sl = getenv("AUDIOMOD_PV_STREAM_LAUNCHES");
+            split_analysis = d.fft.nc == 2048 && !(es && atoi(es) == 0) && !(sl && strcmp(sl, "single") == 0);
+        }
+        if (split_analysis) {
+            std::vector<cf> twc(d.fft.tw_fwd.size());
+            for (size_t i = 0; i < twc.size(); ++i) twc[i] = cf{d.fft.tw_fwd[i].r, d.fft.tw_fwd[i].i};
+            const int entries = wf_lane_table_entries<WF2048S>();
+            std::vector<cf> out(2 * (size_t)entries * WF2048S::LANES);
+            wf_build_lane_table<WF2048S>(twc.data(), out.data());
+            std::vector<float4> o4((size_t)entries * WF2048S::LANES);
+            for (size_t i = 0; i < o4.size(); ++i) o4[i] = make_float4(out[2 * i].x, out[2 * i].y, out[2 * i + 1].x, out[2 * i + 1].y);
+            if ((st = twl_fwd.upload(o4)) != PV_OK) return st;
+        } else if ((st = lane_table(d.fft.tw_fwd, twl_fwd)) != PV_OK) return st;
         if ((st = lane_table(d.fft.tw_inv, twl_inv)) != PV_OK) return st;
     }
     if ((st = up2(st_inv, d.fft.st_inv)) != PV_OK) return st;
@@ -850,6 +866,7 @@ void Core::launch_chunk(const InAddr &ia, int64_t t0, int Tn, const int32_t *d_p
     aa.rows = rows;
     aa.PKP = PKP;
     aa.find_peaks = cm == 1 ? 1 : 0;
+    aa.split = split_analysis ? 1 : 0;
     aa.mag = mag.p;
     aa.phase = phase.p;
     aa.peaks = peaks.p;

@@ -50,6 +50,7 @@ struct AnalyzeArgs {
     int rows;   // S*C
     int PKP;    // pitch of the peak lists
     int find_peaks;
+    int split;       // 4096-point frames on two waves each (tb.twl_fwd then holds WF2048S's lane table)
     float *mag;      // [rows][TR][HP]
     float *phase;    // [rows][TR][HP] analysis phase
     uint16_t *peaks; // [rows][TR][PKP]

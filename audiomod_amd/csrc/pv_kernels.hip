@@ -587,6 +587,265 @@ __device__ __forceinline__ void analyze_wave_role(const AnalyzeArgs &a, const in
     for (int i = lane; 2 * i < running; i += 64) pk32[i] = slist32[i];
 }
 
+// workgroup barrier for hand-overs through LDS: waits for this wave's LDS operations only (a __syncthreads() would also
+// wait for its outstanding global stores to be acknowledged)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The same analysis with a frame on TWO waves (WF2048S: 4096-point frames, 128 lanes x 16 elements): the arithmetic,
+// its order and the outputs are those of analyze_wave_role<2048>; what changes is who holds what.  A lane needs the
+// registers of the 2048-point frame's kernel (four waves per SIMD instead of two), the passes hand over through workgroup
+// barriers, and the peak list's positions need the other wave's counts.  The polar loop overwrites the cartesian bins it
+// has consumed with magnitudes, so each of its iterations separates its reads from its writes by a barrier.
+template <class W, uint32_t ATAB>
+__device__ __forceinline__ void analyze_split_role(const AnalyzeArgs &a, const int row, const int tl, cf *lds) {
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const unsigned char *atab = reinterpret_cast<const unsigned char *>((uintptr_t)ATAB);
+    constexpr int NC = W::N_C, N = 2 * NC, hs = NC, R = W::R, LN = W::LANES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t atab_word = pv_atan_blob_dev.w[lane];
+    const DevTables &tb = a.tb;
+    const int64_t t = a.t0 + tl;
+    const int slot = ring_slot(a.s0, tl, a.TR);
+    const int64_t a0 = t * (int64_t)a.hop;
+    const float *__restrict__ in = a.ia.in + (int64_t)row * a.ia.stride_c;
+    const float *__restrict__ w = tb.window;
+    const cf *__restrict__ tw = reinterpret_cast<const cf *>(tb.tw_fwd);
+    const cf *__restrict__ stw = reinterpret_cast<const cf *>(tb.st_fwd);
+    const cf2 *__restrict__ twl = reinterpret_cast<const cf2 *>(tb.twl_fwd);
+
+    WfTw<W> T0, T1, T2;
+    wf_load_pass_tw<W, 0>(T0, tid, tw);
+    cf v[R];
+    {
+        const int lp = wf_lane_part<W>(0, tid);
+        const int lsrc = wf_src_of<W>(lp);
+        const uint64_t m0 = (uint64_t)a0 & a.ia.mask;
+        if (a0 + N + 4 <= a.ia.len && ((m0 + (uint64_t)(N + 3)) & a.ia.mask) == m0 + (uint64_t)(N + 3)) {
+            // (workgroup-uniform) aligned 16-byte pieces of the span that holds the frame times the window copy delayed
+            // by the frame's offset into its first piece, staged through LDS (analyze_wave_role)
+            const float *__restrict__ fp = in + m0;
+            const uintptr_t fa = reinterpret_cast<uintptr_t>(fp);
+            const int d = (int)((fa & 15u) >> 2);
+            const float4 *__restrict__ xb = reinterpret_cast<const float4 *>(fa & ~(uintptr_t)15);
+            const float4 *__restrict__ wb = reinterpret_cast<const float4 *>(tb.window_sh + (size_t)d * (N + 8));
+            constexpr int Q = N / (4 * LN); // 16-byte pieces per lane (plus one more on thread 0)
+            float4 *stage4 = reinterpret_cast<float4 *>(lds);
+            float4 xt = make_float4(0.f, 0.f, 0.f, 0.f), wt = xt;
+            if (tid == 0) {
+                xt = xb[LN * Q];
+                wt = wb[LN * Q];
+            }
+            float4 xq[Q], wq[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                xq[q] = xb[tid + LN * q];
+                wq[q] = wb[tid + LN * q];
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                stage4[tid + LN * q] = make_float4(xq[q].x * wq[q].x, xq[q].y * wq[q].y, xq[q].z * wq[q].z, xq[q].w * wq[q].w);
+            if (tid == 0) stage4[LN * Q] = make_float4(xt.x * wt.x, xt.y * wt.y, xt.z * wt.z, xt.w * wt.w);
+            lds_barrier();
+            const float *stage = reinterpret_cast<const float *>(lds) + d; // stage[k] = x[a0 + k] * w[k]
+            const int kl = (2 * lsrc + hs) & (N - 1);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int kr = 2 * wf_src_of_const<W>(wf_reg_part<W>(0, r));
+                const int k0 = kl ^ kr;
+                v[r] = cf{stage[k0], stage[k0 + 1]};
+            }
+            lds_barrier(); // (pass 0 stores over the staged frame)
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int src = lsrc | wf_src_of_const<W>(wf_reg_part<W>(0, r));
+                const int k0 = (2 * src + hs) & (N - 1);
+                const int64_t g0 = a0 + k0;
+                const float x0 = g0 < a.ia.len ? in[(uint64_t)g0 & a.ia.mask] : 0.f;
+                const float x1 = g0 + 1 < a.ia.len ? in[(uint64_t)(g0 + 1) & a.ia.mask] : 0.f;
+                v[r] = cf{x0 * w[k0], x1 * w[k0 + 1]};
+            }
+        }
+    }
+    constexpr int J = NC / (2 * LN);
+    const int lp0 = wf_lane_part<W>(0, tid), lp1 = wf_lane_part<W>(1, tid), lp2 = wf_lane_part<W>(2, tid);
+    // (a pass loads exactly the slots it stores, so one barrier per hand-over is enough)
+    WfTwRaw<W, 1> raw1;
+    wf_fetch_pass_tw<W, 1>(raw1, tid, twl);
+    wf_apply_pass_stages<W, 0, false>(v, T0);
+    wf_store<W, 0>(lds, v, lp0);
+    lds_barrier();
+    wf_load<W, 1>(lds, v, lp1);
+    wf_unpack_pass_tw<W, 1>(T1, raw1);
+    wf_apply_pass_stages<W, 1, false>(v, T1);
+    WfTwRaw<W, 2> raw2;
+    wf_fetch_pass_tw<W, 2>(raw2, tid, twl);
+    wf_store<W, 1>(lds, v, lp1);
+    lds_barrier();
+    wf_load<W, 2>(lds, v, lp2);
+    wf_unpack_pass_tw<W, 2>(T2, raw2);
+    wf_apply_pass_stages<W, 2, false>(v, T2);
+    cf sw[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) sw[j] = stw[tid + LN * j];
+    const cf swmid = stw[NC / 2];
+    wf_store<W, 2>(lds, v, lp2);
+    lds_barrier();
+
+    // real-FFT split (kiss_fftr.c:91-120): thread handles k = tid + LN j and NC - k
+    const int64_t plane = ((int64_t)row * a.TR + slot);
+    float *__restrict__ mag = a.mag + plane * tb.HP;
+    float *__restrict__ ph = a.phase + plane * tb.HP;
+    cf xlo[J], xhi[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = tid + LN * j;
+        if (j == 0 && tid == 0) {
+            const cf tdc = lds[W::pad(0)];
+            xlo[0] = cf{tdc.x + tdc.y, 0.f};
+            xhi[0] = cf{tdc.x - tdc.y, 0.f};
+        } else {
+            const cf fpk = lds[W::pad(k)];
+            const cf q = lds[W::pad(NC - k)];
+            const cf fpnk = cf{q.x, -q.y};
+            const cf f1k = wf_add(fpk, fpnk);
+            const cf f2k = wf_sub(fpk, fpnk);
+            const cf tq = wf_cmul(f2k, sw[j]);
+            xlo[j] = cf{(f1k.x + tq.x) * 0.5f, (f1k.y + tq.y) * 0.5f};
+            xhi[j] = cf{(f1k.x - tq.x) * 0.5f, (tq.y - f1k.y) * 0.5f};
+        }
+    }
+    cf xmid = cf{0.f, 0.f};
+    if (tid == 0) {
+        const cf fpk = lds[W::pad(NC / 2)];
+        const cf fpnk = cf{fpk.x, -fpk.y};
+        const cf f1k = wf_add(fpk, fpnk);
+        const cf f2k = wf_sub(fpk, fpnk);
+        const cf tq = wf_cmul(f2k, swmid);
+        xmid = cf{(f1k.x - tq.x) * 0.5f, (tq.y - f1k.y) * 0.5f};
+    }
+    lds_barrier();
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = tid + LN * j;
+        if (j == 0 && tid == 0) {
+            lds[0] = xlo[0];
+            lds[NC] = xhi[0];
+        } else {
+            lds[k] = xlo[j];
+            lds[NC - k] = xhi[j];
+        }
+    }
+    if (tid == 0) lds[NC / 2] = xmid;
+    float *smag = reinterpret_cast<float *>(lds);
+    *(lds_u32 *)(uintptr_t)(ATAB + 4u * (uint32_t)lane) = atab_word; // (both waves, the same words)
+    lds_barrier();
+    float edge_mag = 0.f, edge_ph = 0.f;
+    if (tid < 2) {
+        const cf e = lds[tid == 0 ? 0 : NC];
+        edge_mag = sqrtf(e.x * e.x + 0.f * 0.f);
+        edge_ph = pv_u2f((uint32_t)((int32_t)pv_f2u(e.x) >> 31) & pv_f2u(3.1415927410e+00f));
+    }
+    lds_barrier();
+    if (tid == 0) lds[0] = cf{1.f, 1.f};
+    lds_barrier();
+    constexpr int NQ = NC / (4 * LN);
+#pragma nounroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i4 = 4 * (tid + LN * q);
+        const float4 c01 = *reinterpret_cast<const float4 *>(lds + i4);
+        const float4 c23 = *reinterpret_cast<const float4 *>(lds + i4 + 2);
+        lds_barrier(); // every read of this iteration before any of its writes (the other wave's runs included)
+        float4 m4, p4;
+        const float a0 = c01.x * c01.x + c01.y * c01.y, a1 = c01.z * c01.z + c01.w * c01.w;
+        const float a2 = c23.x * c23.x + c23.y * c23.y, a3 = c23.z * c23.z + c23.w * c23.w;
+        const float mx = __builtin_fmaxf(__builtin_fmaxf(pv_max3_abs(c01.x, c01.y, c01.z), pv_max3_abs(c01.w, c23.x, c23.y)),
+                                         __builtin_fmaxf(__builtin_fabsf(c23.z), __builtin_fabsf(c23.w)));
+        const float mn = __builtin_fminf(__builtin_fminf(pv_min3_abs(c01.x, c01.y, c01.z), pv_min3_abs(c01.w, c23.x, c23.y)),
+                                         __builtin_fminf(__builtin_fabsf(c23.z), __builtin_fabsf(c23.w)));
+        const bool in_range = mx < 0x1p63f && mn >= 0x1p-48f;
+        if (__builtin_amdgcn_ballot_w64(!in_range) == 0) {
+            m4 = make_float4(pv_sqrt_safe(a0), pv_sqrt_safe(a1), pv_sqrt_safe(a2), pv_sqrt_safe(a3));
+            p4.x = pv_atan2f_fd_tab<true>(c01.y, c01.x, atab);
+            p4.y = pv_atan2f_fd_tab<true>(c01.w, c01.z, atab);
+            p4.z = pv_atan2f_fd_tab<true>(c23.y, c23.x, atab);
+            p4.w = pv_atan2f_fd_tab<true>(c23.w, c23.z, atab);
+        } else {
+            m4 = make_float4(sqrtf(a0), sqrtf(a1), sqrtf(a2), sqrtf(a3));
+            p4.x = pv_atan2f_fd_tab<false>(c01.y, c01.x, atab);
+            p4.y = pv_atan2f_fd_tab<false>(c01.w, c01.z, atab);
+            p4.z = pv_atan2f_fd_tab<false>(c23.y, c23.x, atab);
+            p4.w = pv_atan2f_fd_tab<false>(c23.w, c23.z, atab);
+        }
+        if (q == 0 && tid == 0) p4.x = edge_ph, m4.x = edge_mag;
+        *reinterpret_cast<float4 *>(ph + i4) = p4;
+        *reinterpret_cast<float4 *>(mag + i4) = m4;
+        *reinterpret_cast<float4 *>(smag + i4) = m4;
+    }
+    if (tid == 1) {
+        ph[NC] = edge_ph;
+        mag[NC] = edge_mag;
+        smag[NC] = edge_mag;
+    }
+    lds_barrier();
+    if (!a.find_peaks) return; // (workgroup-uniform)
+    // peak list: flags and per-wave counts first, positions once both waves' counts are known (runs in ascending bin
+    // order are (q, wave 0), (q, wave 1), (q + 1, wave 0), ...)
+    uint16_t *slist = reinterpret_cast<uint16_t *>(smag + NC + 4); // [PKP], 16-byte aligned
+    int *scnt = reinterpret_cast<int *>(reinterpret_cast<char *>(lds) + ATAB + 4u * PV_ATAN_BLOB_WORDS); // [2][NQ] behind atan2f's table (lds is the workgroup's LDS base)
+    const float inf = __builtin_inff();
+    int fl[NQ], pre[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i4 = 4 * (tid + LN * q);
+        const float4 m = *reinterpret_cast<const float4 *>(smag + i4);
+        float2 lo = *reinterpret_cast<const float2 *>(smag + (q == 0 && tid == 0 ? 0 : i4 - 2));
+        float2 hi = *reinterpret_cast<const float2 *>(smag + i4 + 4);
+        if (q == 0 && tid == 0) lo = make_float2(inf, inf);
+        if (q == NQ - 1 && tid == LN - 1) hi = make_float2(inf, inf);
+        const float in01 = __builtin_fmaxf(m.x, m.y), in12 = __builtin_fmaxf(m.y, m.z), in23 = __builtin_fmaxf(m.z, m.w);
+        const bool f0 = m.x > __builtin_fmaxf(__builtin_fmaxf(lo.x, lo.y), in12);
+        const bool f1 = m.y > __builtin_fmaxf(__builtin_fmaxf(lo.y, m.x), in23);
+        const bool f2 = m.z > __builtin_fmaxf(in01, __builtin_fmaxf(m.w, hi.x));
+        const bool f3 = m.w > __builtin_fmaxf(in12, __builtin_fmaxf(hi.x, hi.y));
+        const bool any = f0 || f1 || f2 || f3, two = f0 && f3;
+        const unsigned long long ma = __ballot(any), mb = __ballot(two);
+        pre[q] = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0u)) +
+                 (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
+        fl[q] = (any ? 4 : 0) | (two ? 8 : 0) | (f0 ? 0 : f1 ? 1 : f2 ? 2 : 3);
+        if (lane == 0) scnt[wv * NQ + q] = __popcll(ma) + __popcll(mb);
+    }
+    lds_barrier();
+    int running = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c0 = scnt[q], c1 = scnt[NQ + q];
+        const int pos = running + (wv ? c0 : 0) + pre[q];
+        const int i4 = 4 * (tid + LN * q);
+        if (fl[q] & 4) slist[pos] = (uint16_t)(i4 + (fl[q] & 3));
+        if (fl[q] & 8) slist[pos + 1] = (uint16_t)(i4 + 3);
+        running += c0 + c1;
+    }
+    if (tid == 0) {
+        a.npk[plane] = running;
+        if (running & 1) slist[running] = 0; // the odd tail shares a word with the last peak
+    }
+    lds_barrier();
+    uint32_t *__restrict__ pk32 = reinterpret_cast<uint32_t *>(a.peaks + plane * a.PKP); // PKP % 8 == 0
+    const uint32_t *slist32 = reinterpret_cast<const uint32_t *>(slist);
+    for (int i = tid; 2 * i < running; i += LN) pk32[i] = slist32[i];
+}
+
+// one frame per workgroup of two waves
+__global__ __launch_bounds__(128) void pv_analyze_split_kernel(const AnalyzeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PV_POISON_LDS(reinterpret_cast<char *>(smem_raw));
+    int row, tl;
+    if (!block_to_row_slice(a.Tn, a.rows, row, tl)) return; // workgroup-uniform
+    analyze_split_role<WF2048S, WF2048S::LDS_CF * sizeof(cf)>(a, row, tl, reinterpret_cast<cf *>(smem_raw));
+}
+
 // (the 4096-point variant needs 232 VGPRs, two waves per SIMD; forced to three -- 168 registers, 88 spilled -- it is
 // slower: 1.05 vs 0.91 ms per 64 K slices)
 template <int NC, int WPB> __global__ __launch_bounds__(64 * WPB) void pv_analyze_wave_kernel(const AnalyzeArgs a) {
@@ -630,6 +889,12 @@ void launch_analyze(const AnalyzeArgs &a, hipStream_t st) {
             hipLaunchKernelGGL((pv_analyze_wave_kernel<1024, WPB>), dim3(grid), dim3(64 * WPB),
                                WPB * WF<1024>::LDS_CF * sizeof(cf) + 4 * PV_ATAN_BLOB_WORDS, st, a);
         } else {
+            if (a.split) { // a frame on two waves (pv_analyze_split_kernel; tb.twl_fwd is WF2048S's table)
+                const int grid = 8 * ((a.rows + 7) / 8) * a.Tn;
+                hipLaunchKernelGGL(pv_analyze_split_kernel, dim3(grid), dim3(WF2048S::LANES),
+                                   WF2048S::LDS_CF * sizeof(cf) + 4 * PV_ATAN_BLOB_WORDS + 64, st, a);
+                return;
+            }
             constexpr int WPB = 1;
             const int grid = 8 * ((a.rows + 7) / 8) * ((a.Tn + WPB - 1) / WPB);
             static unsigned long long big = 0;

@@ -47,6 +47,7 @@ template <int NC> struct WF;
 // Round 3: 512 complex points (fft 1024), eight elements per lane.  kissfft's stages for 512 are 2, 4, 4, 4, 4; with
 // three register bits per pass a radix-4 stage fills a pass on its own from the second one on: FOUR passes (NPASS).
 template <> struct WF<512> {
+    static constexpr int LB = 6, LANES = 64; // lane bits: one wave per transform
     static constexpr int N_C = 512, LOG = 9, R = 8, RB = 3, NSTAGE = 5, NPASS = 4;
     static constexpr int st_radix[6] = {2, 4, 4, 4, 4, 0};
     static constexpr int st_bit[6] = {0, 1, 3, 5, 7, 0};
@@ -61,6 +62,7 @@ template <> struct WF<512> {
 
 // ... and 256 complex points (fft 512), four elements per lane: kissfft's 4 4 4 4, one stage per pass.
 template <> struct WF<256> {
+    static constexpr int LB = 6, LANES = 64; // lane bits: one wave per transform
     static constexpr int N_C = 256, LOG = 8, R = 4, RB = 2, NSTAGE = 4, NPASS = 4;
     static constexpr int st_radix[6] = {4, 4, 4, 4, 0, 0};
     static constexpr int st_bit[6] = {0, 2, 4, 6, 0, 0};
@@ -74,6 +76,7 @@ template <> struct WF<256> {
 };
 
 template <> struct WF<1024> {
+    static constexpr int LB = 6, LANES = 64; // lane bits: one wave per transform
     static constexpr int N_C = 1024, LOG = 10, R = 16, RB = 4, NSTAGE = 5, NPASS = 3;
     static constexpr int st_radix[6] = {4, 4, 4, 4, 4, 0};
     static constexpr int st_bit[6] = {0, 2, 4, 6, 8, 0};
@@ -87,6 +90,7 @@ template <> struct WF<1024> {
 };
 
 template <> struct WF<2048> {
+    static constexpr int LB = 6, LANES = 64; // lane bits: one wave per transform
     static constexpr int N_C = 2048, LOG = 11, R = 32, RB = 5, NSTAGE = 6, NPASS = 3;
     static constexpr int st_radix[6] = {2, 4, 4, 4, 4, 4};
     static constexpr int st_bit[6] = {0, 1, 3, 5, 7, 9};
@@ -94,6 +98,23 @@ template <> struct WF<2048> {
     static constexpr int regpos[4][5] = {{0, 1, 2, 3, 4}, {0, 5, 6, 7, 8}, {0, 7, 8, 9, 10}, {0, 0, 0, 0, 0}};
     static constexpr int lanepos[4][6] = {{5, 6, 7, 8, 9, 10}, {1, 2, 3, 4, 9, 10}, {1, 2, 3, 4, 5, 6}, {0, 0, 0, 0, 0, 0}};
     // e = b + 2 (d1 + 4 d2 + 16 d3 + 64 d4 + 256 d5)  <-  src = d5 + 4 d4 + 16 d3 + 64 d2 + 256 d1 + 1024 b
+    static constexpr int srcbit[11] = {10, 8, 9, 6, 7, 4, 5, 2, 3, 0, 1};
+    static PV_HD int pad(int e) { return e + (e >> 4) + (e >> 8); }
+    static constexpr int LDS_CF = 2048 + 128 + 8 + 8;
+};
+
+// 2048 complex points (fft 4096) on TWO waves: 128 lanes x 16 elements, so that a lane needs the registers of the
+// 1024-point transform (four waves per SIMD instead of two) and a frame's latency is shared by twice the waves.  Same
+// stages, same arithmetic, same leaf permutation as WF<2048>; the passes are separated by workgroup barriers.
+// (pass 0 keeps element bit 3 in a register without using it: stages 0 and 1 need three register bits)
+struct WF2048S {
+    static constexpr int LB = 7, LANES = 128;
+    static constexpr int N_C = 2048, LOG = 11, R = 16, RB = 4, NSTAGE = 6, NPASS = 3;
+    static constexpr int st_radix[6] = {2, 4, 4, 4, 4, 4};
+    static constexpr int st_bit[6] = {0, 1, 3, 5, 7, 9};
+    static constexpr int st_pass[6] = {0, 0, 1, 1, 2, 2};
+    static constexpr int regpos[4][5] = {{0, 1, 2, 3, 0}, {3, 4, 5, 6, 0}, {7, 8, 9, 10, 0}, {0, 0, 0, 0, 0}};
+    static constexpr int lanepos[4][7] = {{4, 5, 6, 7, 8, 9, 10}, {0, 1, 2, 7, 8, 9, 10}, {0, 1, 2, 3, 4, 5, 6}, {0, 0, 0, 0, 0, 0, 0}};
     static constexpr int srcbit[11] = {10, 8, 9, 6, 7, 4, 5, 2, 3, 0, 1};
     static PV_HD int pad(int e) { return e + (e >> 4) + (e >> 8); }
     static constexpr int LDS_CF = 2048 + 128 + 8 + 8;
@@ -132,7 +153,7 @@ template <class W> PV_HD int wf_e_of_src(int s) {
 template <class W> PV_HD int wf_lane_part(int pass, int lane) {
     int e = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) e |= ((lane >> i) & 1) << W::lanepos[pass][i];
+    for (int i = 0; i < W::LB; ++i) e |= ((lane >> i) & 1) << W::lanepos[pass][i];
     return e;
 }
 
@@ -280,7 +301,7 @@ template <class W> constexpr int wf_lane_table_entries() {
 
 // host: fill out[(entry * 64 + lane) * 2 + (slot & 1)] for passes 1 and 2 (out: 2 * entries * 64 values)
 template <class W> inline void wf_build_lane_table(const cf *tw, cf *out) {
-    for (int i = 0; i < 2 * wf_lane_table_entries<W>() * 64; ++i) out[i] = cf{0.f, 0.f};
+    for (int i = 0; i < 2 * wf_lane_table_entries<W>() * W::LANES; ++i) out[i] = cf{0.f, 0.f};
     for (int pass = 1; pass < W::NPASS; ++pass) {
         int base4 = 0;
         for (int q = 1; q < pass; ++q) base4 += wf_pass_entries<W>(q);
@@ -294,11 +315,11 @@ template <class W> inline void wf_build_lane_table(const cf *tw, cf *out) {
                 if (wf_stage_first_reg<W>(s, r) != r) continue;
                 for (int q = 1; q < radix; ++q) {
                     const int slot = wf_slot_in_pass<W>(pass, s, r, q);
-                    for (int lane = 0; lane < 64; ++lane) {
+                    for (int lane = 0; lane < W::LANES; ++lane) {
                         int lp = 0;
-                        for (int i = 0; i < 6; ++i) lp |= ((lane >> i) & 1) << W::lanepos[pass][i];
+                        for (int i = 0; i < W::LB; ++i) lp |= ((lane >> i) & 1) << W::lanepos[pass][i];
                         const int k = (lp + wf_reg_part<W>(pass, r)) & (m - 1);
-                        out[((base4 + slot / 2) * 64 + lane) * 2 + (slot & 1)] = tw[q * k * fs];
+                        out[((base4 + slot / 2) * W::LANES + lane) * 2 + (slot & 1)] = tw[q * k * fs];
                     }
                 }
             }
@@ -316,7 +337,7 @@ template <class W, int P> struct WfTwRaw {
 template <class W, int P> PV_HD void wf_fetch_pass_tw(WfTwRaw<W, P> &raw, int lane, const cf2 *__restrict__ table) {
     constexpr int NE = wf_pass_entries<W>(P), B4 = wf_pass_base4<W, P>();
 #pragma unroll
-    for (int j = 0; j < NE; ++j) raw.e[j] = table[(B4 + j) * 64 + lane];
+    for (int j = 0; j < NE; ++j) raw.e[j] = table[(B4 + j) * W::LANES + lane];
 }
 // (register and factor indices are template parameters so that every slot number is a compile-time constant)
 template <class W, int P, int S, int RR, int Q> PV_HD void wf_unpack_one_tw(cf (&t)[W::R], const WfTwRaw<W, P> &raw) {

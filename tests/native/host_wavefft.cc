@@ -1,5 +1,5 @@
 // tests/native/host_wavefft.cc -- CPU check of the wave-FFT core's index math (audiomod_amd/csrc/pv_wavefft.h).
-// Runs the exact __host__ __device__ code lane by lane (64 emulated lanes, a plain array as the
+// Runs the exact __host__ __device__ code lane by lane (64 emulated lanes -- 128 for the two-wave spec --, a plain array as the
 // wave-private LDS region) and compares, bit for bit, with the straightforward permutation +
 // level-by-level butterflies over the same plan tables (which the oracle pins to the reference).
 // Build: g++ -O2 -std=c++17 -ffp-contract=off -Iinclude -Iaudiomod_amd/csrc tests/native/host_wavefft.cc \
@@ -35,8 +35,8 @@ static void ref_fft(const FftPlan &p, const std::vector<cf> &tw, bool inv, const
     }
 }
 
-template <int NC, bool INV> static int check(unsigned seed) {
-    using W = WF<NC>;
+template <class W, bool INV> static int check_spec(unsigned seed, const char *label) {
+    constexpr int NC = W::N_C, LANES = W::LANES;
     pv_config cfg{48000, 1, 1.0f, 4.0f, 0, 1, 2 * NC, 0};
     Derived d;
     if (derive(cfg, d) != PV_OK) return 1;
@@ -54,25 +54,25 @@ template <int NC, bool INV> static int check(unsigned seed) {
     in[3] = cf{0.f, -0.f};
     ref_fft(d.fft, tw, INV, in, want);
     std::vector<cf> lds(W::LDS_CF, cf{0, 0});
-    std::vector<std::vector<cf>> regs(64, std::vector<cf>(W::R));
+    
     // pass 0: load in pass-0 layout straight from the source array
-    for (int lane = 0; lane < 64; ++lane) {
+    for (int lane = 0; lane < LANES; ++lane) {
         cf v[W::R];
         const int lp = wf_lane_part<W>(0, lane);
         for (int r = 0; r < W::R; ++r) v[r] = in[wf_src_of<W>(lp | wf_reg_part<W>(0, r))];
         wf_fft_pass<W, 0, INV>(v, lane, lds.data(), tw.data());
     }
-    for (int lane = 0; lane < 64; ++lane) { cf v[W::R]; wf_fft_pass<W, 1, INV>(v, lane, lds.data(), tw.data()); }
-    for (int lane = 0; lane < 64; ++lane) { cf v[W::R]; wf_fft_pass<W, 2, INV>(v, lane, lds.data(), tw.data()); }
+    for (int lane = 0; lane < LANES; ++lane) { cf v[W::R]; wf_fft_pass<W, 1, INV>(v, lane, lds.data(), tw.data()); }
+    for (int lane = 0; lane < LANES; ++lane) { cf v[W::R]; wf_fft_pass<W, 2, INV>(v, lane, lds.data(), tw.data()); }
     if constexpr (W::NPASS == 4)
-        for (int lane = 0; lane < 64; ++lane) { cf v[W::R]; wf_fft_pass<W, 3, INV>(v, lane, lds.data(), tw.data()); }
+        for (int lane = 0; lane < LANES; ++lane) { cf v[W::R]; wf_fft_pass<W, 3, INV>(v, lane, lds.data(), tw.data()); }
     for (int e = 0; e < NC; ++e) {
         const cf g = lds[W::pad(e)];
         if (memcmp(&g, &want[e], sizeof(cf)) != 0) ++bad;
     }
     // the same transform through the prefetched-twiddle entry points the kernels use
     std::fill(lds.begin(), lds.end(), cf{0, 0});
-    for (int lane = 0; lane < 64; ++lane) {
+    for (int lane = 0; lane < LANES; ++lane) {
         cf v[W::R];
         WfTw<W> T;
         const int lp = wf_lane_part<W>(0, lane);
@@ -80,20 +80,20 @@ template <int NC, bool INV> static int check(unsigned seed) {
         wf_load_pass_tw<W, 0>(T, lane, tw.data());
         wf_fft_pass_tw<W, 0, INV>(v, lane, lds.data(), T);
     }
-    for (int lane = 0; lane < 64; ++lane) {
+    for (int lane = 0; lane < LANES; ++lane) {
         cf v[W::R];
         WfTw<W> T;
         wf_load_pass_tw<W, 1>(T, lane, tw.data());
         wf_fft_pass_tw<W, 1, INV>(v, lane, lds.data(), T);
     }
-    for (int lane = 0; lane < 64; ++lane) {
+    for (int lane = 0; lane < LANES; ++lane) {
         cf v[W::R];
         WfTw<W> T;
         wf_load_pass_tw<W, 2>(T, lane, tw.data());
         wf_fft_pass_tw<W, 2, INV>(v, lane, lds.data(), T);
     }
     if constexpr (W::NPASS == 4)
-        for (int lane = 0; lane < 64; ++lane) {
+        for (int lane = 0; lane < LANES; ++lane) {
             cf v[W::R];
             WfTw<W> T;
             wf_load_pass_tw<W, 3>(T, lane, tw.data());
@@ -104,11 +104,11 @@ template <int NC, bool INV> static int check(unsigned seed) {
         if (memcmp(&g, &want[e], sizeof(cf)) != 0) ++bad;
     }
     // and with passes 1 and 2 taking their twiddles from the lane-major table the engine uploads
-    std::vector<cf> table(2 * (size_t)wf_lane_table_entries<W>() * 64);
+    std::vector<cf> table(2 * (size_t)wf_lane_table_entries<W>() * LANES);
     wf_build_lane_table<W>(tw.data(), table.data());
     const cf2 *tab2 = reinterpret_cast<const cf2 *>(table.data());
     std::fill(lds.begin(), lds.end(), cf{0, 0});
-    for (int lane = 0; lane < 64; ++lane) {
+    for (int lane = 0; lane < LANES; ++lane) {
         cf v[W::R];
         WfTw<W> T;
         const int lp = wf_lane_part<W>(0, lane);
@@ -116,7 +116,7 @@ template <int NC, bool INV> static int check(unsigned seed) {
         wf_load_pass_tw<W, 0>(T, lane, tw.data());
         wf_fft_pass_tw<W, 0, INV>(v, lane, lds.data(), T);
     }
-    for (int lane = 0; lane < 64; ++lane) {
+    for (int lane = 0; lane < LANES; ++lane) {
         cf v[W::R];
         WfTw<W> T;
         WfTwRaw<W, 1> raw;
@@ -124,7 +124,7 @@ template <int NC, bool INV> static int check(unsigned seed) {
         wf_unpack_pass_tw<W, 1>(T, raw);
         wf_fft_pass_tw<W, 1, INV>(v, lane, lds.data(), T);
     }
-    for (int lane = 0; lane < 64; ++lane) {
+    for (int lane = 0; lane < LANES; ++lane) {
         cf v[W::R];
         WfTw<W> T;
         WfTwRaw<W, 2> raw;
@@ -133,7 +133,7 @@ template <int NC, bool INV> static int check(unsigned seed) {
         wf_fft_pass_tw<W, 2, INV>(v, lane, lds.data(), T);
     }
     if constexpr (W::NPASS == 4)
-        for (int lane = 0; lane < 64; ++lane) {
+        for (int lane = 0; lane < LANES; ++lane) {
             cf v[W::R];
             WfTw<W> T;
             WfTwRaw<W, 3> raw;
@@ -148,7 +148,7 @@ template <int NC, bool INV> static int check(unsigned seed) {
     // ... and the free-form (PV_ARITH_FAST) stages: same transform, fma products and literal twiddles where the twiddle
     // index lives in register bits -- equal to the exact result up to rounding (relative to the spectrum's RMS)
     std::fill(lds.begin(), lds.end(), cf{0, 0});
-    for (int lane = 0; lane < 64; ++lane) {
+    for (int lane = 0; lane < LANES; ++lane) {
         cf v[W::R];
         WfTw<W> T;
         const int lp = wf_lane_part<W>(0, lane);
@@ -157,7 +157,7 @@ template <int NC, bool INV> static int check(unsigned seed) {
         wf_apply_pass_stages_fast<W, 0, INV>(v, T);
         wf_store<W, 0>(lds.data(), v, lp);
     }
-    for (int lane = 0; lane < 64; ++lane) {
+    for (int lane = 0; lane < LANES; ++lane) {
         cf v[W::R];
         WfTw<W> T;
         const int lp = wf_lane_part<W>(1, lane);
@@ -166,7 +166,7 @@ template <int NC, bool INV> static int check(unsigned seed) {
         wf_apply_pass_stages_fast<W, 1, INV>(v, T);
         wf_store<W, 1>(lds.data(), v, lp);
     }
-    for (int lane = 0; lane < 64; ++lane) {
+    for (int lane = 0; lane < LANES; ++lane) {
         cf v[W::R];
         WfTw<W> T;
         const int lp = wf_lane_part<W>(2, lane);
@@ -176,7 +176,7 @@ template <int NC, bool INV> static int check(unsigned seed) {
         wf_store<W, 2>(lds.data(), v, lp);
     }
     if constexpr (W::NPASS == 4)
-        for (int lane = 0; lane < 64; ++lane) {
+        for (int lane = 0; lane < LANES; ++lane) {
             cf v[W::R];
             WfTw<W> T;
             const int lp = wf_lane_part<W>(3, lane);
@@ -193,11 +193,13 @@ template <int NC, bool INV> static int check(unsigned seed) {
     }
     const double rel = std::sqrt(err / ref);
     if (!(rel < 2e-7)) ++bad;
-    printf("NC %d inv %d: %s (%d mismatches; lane table %d + %d (+ %d) slots; free-form stages: relative RMS %.2e, pass 0 %s)\n", NC,
+    printf("NC %d%s inv %d: %s (%d mismatches; lane table %d + %d (+ %d) slots; free-form stages: relative RMS %.2e, pass 0 %s)\n", NC, label,
            (int)INV, bad ? "FAIL" : "bit-exact", bad, wf_pass_slots<W>(1), wf_pass_slots<W>(2), W::NPASS == 4 ? wf_pass_slots<W>(3) : 0, rel,
            wf_pass_all_const<W, 0>() ? "all literal twiddles" : "fetched twiddles");
     return bad != 0;
 }
+
+template <int NC, bool INV> static int check(unsigned seed) { return check_spec<WF<NC>, INV>(seed, ""); }
 
 int main() {
     int rc = 0;
@@ -209,5 +211,7 @@ int main() {
     rc |= check<1024, true>(2);
     rc |= check<2048, false>(3);
     rc |= check<2048, true>(4);
+    rc |= check_spec<WF2048S, false>(9, " on two waves");
+    rc |= check_spec<WF2048S, true>(10, " on two waves");
     return rc;
 }
