@@ -726,12 +726,19 @@ __device__ __forceinline__ void analyze_split_role(const AnalyzeArgs &a, const i
         xmid = cf{(f1k.x - tq.x) * 0.5f, (tq.y - f1k.y) * 0.5f};
     }
     lds_barrier();
+    // DC and Nyquist (zero imaginary part by construction, kiss_fftr.c:97-102: atan2f(+0, r) is +0 or pi by r's sign bit,
+    // the magnitude sqrtf(r r + 0 0)) are thread 0's own values; the loop below sees (1, 1) in the DC slot, so that its
+    // operand-range test is not tripped by that zero in every frame
+    float dc_mag = 0.f, dc_ph = 0.f, ny_mag = 0.f, ny_ph = 0.f;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int k = tid + LN * j;
         if (j == 0 && tid == 0) {
-            lds[0] = xlo[0];
-            lds[NC] = xhi[0];
+            dc_mag = sqrtf(xlo[0].x * xlo[0].x + 0.f * 0.f);
+            dc_ph = pv_u2f((uint32_t)((int32_t)pv_f2u(xlo[0].x) >> 31) & pv_f2u(3.1415927410e+00f));
+            ny_mag = sqrtf(xhi[0].x * xhi[0].x + 0.f * 0.f);
+            ny_ph = pv_u2f((uint32_t)((int32_t)pv_f2u(xhi[0].x) >> 31) & pv_f2u(3.1415927410e+00f));
+            lds[0] = cf{1.f, 1.f};
         } else {
             lds[k] = xlo[j];
             lds[NC - k] = xhi[j];
@@ -741,22 +748,23 @@ __device__ __forceinline__ void analyze_split_role(const AnalyzeArgs &a, const i
     float *smag = reinterpret_cast<float *>(lds);
     *(lds_u32 *)(uintptr_t)(ATAB + 4u * (uint32_t)lane) = atab_word; // (both waves, the same words)
     lds_barrier();
-    float edge_mag = 0.f, edge_ph = 0.f;
-    if (tid < 2) {
-        const cf e = lds[tid == 0 ? 0 : NC];
-        edge_mag = sqrtf(e.x * e.x + 0.f * 0.f);
-        edge_ph = pv_u2f((uint32_t)((int32_t)pv_f2u(e.x) >> 31) & pv_f2u(3.1415927410e+00f));
-    }
-    lds_barrier();
-    if (tid == 0) lds[0] = cf{1.f, 1.f};
-    lds_barrier();
+    // Polar conversion, four runs of four bins per thread.  Iteration q writes its magnitudes over the cartesian values of
+    // runs [64 q, 64 q + 64), which iterations 0 and 1 read -- the other wave's threads among them -- and the reads of
+    // those two iterations are issued before the one barrier below; the runs of iterations 2 and 3 are never overwritten.
     constexpr int NQ = NC / (4 * LN);
+    static_assert(NQ <= 4, "the hazard argument above");
+    float4 nx01 = *reinterpret_cast<const float4 *>(lds + 4 * tid), nx23 = *reinterpret_cast<const float4 *>(lds + 4 * tid + 2);
+    float4 nn01 = *reinterpret_cast<const float4 *>(lds + 4 * (tid + LN)), nn23 = *reinterpret_cast<const float4 *>(lds + 4 * (tid + LN) + 2);
+    lds_barrier();
 #pragma nounroll
     for (int q = 0; q < NQ; ++q) {
         const int i4 = 4 * (tid + LN * q);
-        const float4 c01 = *reinterpret_cast<const float4 *>(lds + i4);
-        const float4 c23 = *reinterpret_cast<const float4 *>(lds + i4 + 2);
-        lds_barrier(); // every read of this iteration before any of its writes (the other wave's runs included)
+        const float4 c01 = nx01, c23 = nx23;
+        nx01 = nn01, nx23 = nn23;
+        if (q + 2 < NQ) {
+            nn01 = *reinterpret_cast<const float4 *>(lds + i4 + 8 * LN);
+            nn23 = *reinterpret_cast<const float4 *>(lds + i4 + 8 * LN + 2);
+        }
         float4 m4, p4;
         const float a0 = c01.x * c01.x + c01.y * c01.y, a1 = c01.z * c01.z + c01.w * c01.w;
         const float a2 = c23.x * c23.x + c23.y * c23.y, a3 = c23.z * c23.z + c23.w * c23.w;
@@ -778,15 +786,15 @@ __device__ __forceinline__ void analyze_split_role(const AnalyzeArgs &a, const i
             p4.z = pv_atan2f_fd_tab<false>(c23.y, c23.x, atab);
             p4.w = pv_atan2f_fd_tab<false>(c23.w, c23.z, atab);
         }
-        if (q == 0 && tid == 0) p4.x = edge_ph, m4.x = edge_mag;
+        if (q == 0 && tid == 0) p4.x = dc_ph, m4.x = dc_mag;
         *reinterpret_cast<float4 *>(ph + i4) = p4;
         *reinterpret_cast<float4 *>(mag + i4) = m4;
         *reinterpret_cast<float4 *>(smag + i4) = m4;
     }
-    if (tid == 1) {
-        ph[NC] = edge_ph;
-        mag[NC] = edge_mag;
-        smag[NC] = edge_mag;
+    if (tid == 0) {
+        ph[NC] = ny_ph;
+        mag[NC] = ny_mag;
+        smag[NC] = ny_mag; // (over cartesian bin NC / 2, which only this thread read, two iterations ago)
     }
     lds_barrier();
     if (!a.find_peaks) return; // (workgroup-uniform)
