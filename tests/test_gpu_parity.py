@@ -829,3 +829,40 @@ def test_fft512_and_1024_run_through_the_wave_per_frame_kernels(kw, fftsize, ari
     assert bits_equal(o[0], got) and bits_equal(o[S - 1], got)
     if kw.get("mode") == "robotic":
         assert bits_equal(got, want.astype(np.float32))
+
+
+FFT4096 = [dict(mode="time_stretch", time_ratio=1.5, flush=False), dict(semitones=4.0), dict(semitones=-3.0, coremode=0),
+           dict(mode="formant_pitchshift", semitones=5.0), dict(mode="robotic")]
+
+
+@pytest.mark.parametrize("kw", FFT4096, ids=[str(i) for i in range(len(FFT4096))])
+def test_fft4096_analysis_on_two_waves_equals_the_one_wave_kernel_bit_for_bit(kw, monkeypatch):
+    """Round 3: the analysis kernel of 4096-point frames runs a frame on TWO waves (pv_analyze_split_kernel, pv_wavefft.h
+    WF2048S: 128 lanes x 16 elements; the spec is checked bit for bit on the host, tests/native/host_wavefft.cc).  Same
+    arithmetic in the same order, so under PV_ARITH_EXACT the whole output -- streaming API, with its short first and last
+    calls, and a batch whose last frames run past the input's end (the edge path of the frame load) -- is bit-identical
+    to the one-wave kernel's (AUDIOMOD_PV_SPLIT_ANALYSIS=0), and within the contract of the oracle."""
+    import torch
+    kw = dict(kw, fftsize=4096)
+    flush = kw.pop("flush", True)
+    x = signals.voice(41000, 2, seed=91)
+    prev = E.get_arithmetic()
+    outs = {}
+    try:
+        E.set_arithmetic(E.ARITH_EXACT)
+        for split in ("0", "1"):
+            monkeypatch.setenv("AUDIOMOD_PV_SPLIT_ANALYSIS", split)   # read when an engine is created
+            got, gc = E.run_offline(x, flush=flush, **kw)
+            S = 3
+            b = E.Batch(S, x.shape[1], channels=2, flush=flush, **kw)
+            o = b.run(torch.from_numpy(np.stack([x] * S)).cuda())
+            torch.cuda.synchronize()
+            outs[split] = (got, gc, o.cpu().numpy())
+            b.close()
+    finally:
+        E.set_arithmetic(prev)
+    want, wc, _ = O.run_offline(x, flush=flush, **kw)
+    (g0, c0, b0), (g1, c1, b1) = outs["0"], outs["1"]
+    assert c0 == c1 == wc and g0.shape == g1.shape == want.shape
+    assert bits_equal(g0, g1) and bits_equal(b0, b1)
+    assert rms(g1, want) <= RMS_TOL and rms(b1[2], want) <= RMS_TOL

@@ -17,7 +17,7 @@ from collections import defaultdict
 
 def canonical(k):
     """pv_analyze_wave_kernel<1024, 1> and friends are reported under the stage's kernel name"""
-    if k.startswith("pv_analyze_wave_kernel"):
+    if k.startswith("pv_analyze_wave_kernel") or k.startswith("pv_analyze_split_kernel"):
         return "pv_analyze_kernel"
     if k.startswith("pv_synth_wave_kernel"):
         return "pv_synth_kernel"
