@@ -1,3 +1,8 @@
+#!/bin/bash
+# The round's measurement set, first gpurun call (~6 min of box time): GPU test suite, tools/profile_round.sh (bench line,
+# rocprofv3 kernel stats, FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes -> traffic.json, valu.json), every BASELINE config,
+# the batch-size sweep, the drop-in single-stream bench, the host-memory bench, PV_ARITH_EXACT.  Outputs: gpurun_out/r03/z_*;
+# copy z_traffic.json / z_valu.json to profiles/ (their source hash must match the committed kernels) and the rest to profiles/r03/.
 mkdir -p gpurun_out/r03
 python -m pytest tests -m gpu -x -q > gpurun_out/r03/z_gpu_tests.txt 2>&1; echo "suite rc $?"; tail -3 gpurun_out/r03/z_gpu_tests.txt
 bash tools/profile_round.sh r03/z

@@ -1,3 +1,7 @@
+#!/bin/bash
+# Second gpurun call, after profiles/traffic.json and valu.json have been refreshed: the bench line in the driver's form (now
+# quoting the counters), the parity suite on the -DPV_POISON build (tools/build_variant.sh poison -DPV_POISON first), rocprofv3
+# kernel stats of cfg3 and cfg4, the FFT-size sweep.
 mkdir -p gpurun_out/r03
 timeout -k 10 300 python bench.py --gpus 1 --steps 10 --warmup 3 > gpurun_out/r03/zz_bench_driver_form.json 2> gpurun_out/r03/zz_bench.err; python - <<'PY'
 import json
